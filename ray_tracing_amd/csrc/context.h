@@ -1,0 +1,49 @@
+// rt_ctx: per-GPU context (device scene, stream, scratch pools) shared by the device sources.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "device_scene.h"
+
+namespace rth {
+void set_error(const char* fmt, ...);
+}
+
+#define RT_HIP(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            rth::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RT_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+constexpr int RT_BLOCK = 256;      // threads per workgroup in the traversal kernels (4 waves)
+constexpr int RT_STACK_LDS = 32;   // traversal-stack entries per lane kept in LDS (32 KiB/block)
+constexpr int RT_TRACE_GRID = 2048;  // workgroups of the grid-stride trace kernels (8 per CU)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);  // grow-only
+    void release();
+};
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool has_scene = false;
+    rtd::DScene scene{};  // host copy of the kernel argument
+    DevBuf pairs, tris, objects, materials, lights, media;
+    DevBuf overflow;      // traversal-stack overflow strips
+    uint32_t overflow_levels = 0;
+    DevBuf staging[16];   // rt_trace_* host<->device staging
+    // rt_render state
+    DevBuf path_state, queues, counters, sample_sum;
+    uint64_t max_paths_in_flight = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes);

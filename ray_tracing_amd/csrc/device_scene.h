@@ -1,0 +1,334 @@
+// Device-resident scene layout (what rt_upload_scene builds in HBM) and the intersection routines.
+//
+// Layout, chosen for gfx950 memory transactions rather than for the reference's pointer graph:
+//   * BVH nodes are stored as CHILD PAIRS.  The reference keeps the two children of a node adjacent
+//     (bvh.rs:5-12) but the array starts with the singleton root, so every pair straddles a 64-byte
+//     line.  Here the root's fields live in the object record and pair p (reference nodes 2p+1,
+//     2p+2 of the mesh) sits at byte 64*p: one internal-node visit = one aligned 64-byte fetch.
+//   * A child reference is one u32: bit 31 = leaf, low bits = pair index (internal) or first
+//     triangle (leaf).  That is all a traversal-stack entry has to hold (4 bytes in LDS).
+//   * Triangles are in leaf order, 48 bytes each: (v0, prim_id) (e1, last-in-leaf flag) (e2, 0),
+//     e1 = v1-v0 and e2 = v2-v0 precomputed with the same f32 subtraction the reference performs
+//     per test (primitives.rs:147-148).  A leaf is walked until the flag, so no count is needed.
+#pragma once
+#include "../../include/rt_amd.h"
+#include "device_math.h"
+
+namespace rtd {
+
+constexpr uint32_t LEAF_BIT = 0x80000000u;
+
+struct __attribute__((aligned(32))) DNode {  // one child: 32 bytes
+    float lo[3];
+    float hi[3];
+    uint32_t ref;       // LEAF_BIT | first triangle (global, leaf order)  or  pair index (global)
+    uint32_t num_prim;  // Node.num_prim (bvh.rs:17); informational on the device
+};
+struct __attribute__((aligned(64))) DPair {
+    DNode c[2];
+};
+
+struct DObject {
+    uint32_t kind;           // enum rt_surface_kind
+    uint32_t root_ref;       // RT_SURF_MESH: child reference of the root node
+    uint32_t has_transform;
+    uint32_t material;
+    float surf[12];          // SPHERE c,r / PLANE n,d / TRIANGLE v0,e1,e2 / unused
+    float inv_m[9];          // stored inverse transform (object.rs:25)
+    float inv_t[3];
+    int32_t medium_inside, medium_outside;
+    uint32_t has_medium_interface;
+    uint32_t pad;
+};
+
+struct DScene {
+    const DPair* pairs;
+    const float4* tris;  // 3 float4 per triangle
+    const DObject* objects;
+    const rt_material* materials;
+    const rt_light* lights;
+    const rt_medium* media;
+    uint32_t n_objects, n_lights, n_media, n_materials;
+    rt_camera_flat camera;
+    int32_t initial_medium;
+    uint32_t stack_need;  // deepest traversal stack any mesh of the scene can need
+};
+
+struct Hit {  // SurfaceIntersection (traits.rs:13-17) + ids
+    float t;
+    V3 normal;
+    uint32_t front_face;
+    uint32_t prim;  // original triangle index in its mesh
+    uint32_t obj;
+};
+
+struct Visits {
+    uint32_t n_int, n_tri;
+};
+
+// Per-lane traversal stack: the first STACK_LDS entries in LDS ([level][thread]: a lane's level l
+// is at bank (l*BLOCK + tid) % 32 = tid % 32, so divergent depths never conflict), deeper entries
+// in a per-lane global overflow strip (only trees deeper than STACK_LDS ever touch it).
+template <int STACK_LDS, int BLOCK>
+struct Stack {
+    uint32_t* lds;        // &shared[0][threadIdx.x]
+    uint32_t* overflow;   // &overflow[global lane], stride = overflow_stride
+    uint32_t overflow_stride;
+    int sp;
+    RT_DEV void push(uint32_t v) {
+        if (sp < STACK_LDS) lds[sp * BLOCK] = v;
+        else overflow[(size_t)(sp - STACK_LDS) * overflow_stride] = v;
+        ++sp;
+    }
+    RT_DEV uint32_t pop() {
+        --sp;
+        return sp < STACK_LDS ? lds[sp * BLOCK] : overflow[(size_t)(sp - STACK_LDS) * overflow_stride];
+    }
+};
+
+// AxisAlignedBoundingBox::hit (primitives.rs:304-321).  t_min only grows and t_max only shrinks
+// over the three axes, so the per-axis early return is equivalent to one test at the end.
+RT_DEV bool aabb_hit(const float* lo, const float* hi, V3 o, V3 inv, float t_min, float t_max, float* t_entry) {
+    {
+        float t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
+        bool neg = inv.x < 0.0f;
+        t_min = fmaxf(t_min, neg ? t1 : t0);
+        t_max = fminf(t_max, neg ? t0 : t1);
+    }
+    {
+        float t0 = (lo[1] - o.y) * inv.y, t1 = (hi[1] - o.y) * inv.y;
+        bool neg = inv.y < 0.0f;
+        t_min = fmaxf(t_min, neg ? t1 : t0);
+        t_max = fminf(t_max, neg ? t0 : t1);
+    }
+    {
+        float t0 = (lo[2] - o.z) * inv.z, t1 = (hi[2] - o.z) * inv.z;
+        bool neg = inv.z < 0.0f;
+        t_min = fmaxf(t_min, neg ? t1 : t0);
+        t_max = fminf(t_max, neg ? t0 : t1);
+    }
+    *t_entry = t_min;
+    return !(t_max <= t_min);
+}
+
+// triangle_intersection (primitives.rs:138-186) with e1, e2 given.  The rejections are evaluated
+// as one predicate; each comparison is the reference's, so NaNs fall the same way.
+RT_DEV bool tri_hit(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float t_min, float t_max, float* t_out, float* det_out) {
+    V3 p = cross(d, e2);
+    float det = dot(e1, p);
+    float inv_det = 1.0f / det;
+    V3 s = o - v0;
+    float u = inv_det * dot(s, p);
+    V3 q = cross(s, e1);
+    float v = inv_det * dot(d, q);
+    float t = inv_det * dot(e2, q);
+    bool ok = !(fabsf(det) < F32_EPSILON) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
+              (t > t_min && t < t_max);
+    *t_out = t;
+    *det_out = det;
+    return ok;
+}
+
+// BoundingVolumeHierarchy::traverse_bvh (bvh.rs:243-300).  Same visiting order: a leaf's
+// primitives in `indices` order; both children box-tested with the current t_max; far child
+// pushed, near child taken next, near = child1 unless t1 > t2; popped nodes are not re-culled.
+// "Push near then pop it" is folded into continuing with the near child.
+template <bool ANY, bool COUNT, int STACK_LDS, int BLOCK>
+RT_DEV bool traverse_bvh(const DScene& sc, uint32_t root_ref, V3 o, V3 d, float t_min, float& t_max,
+                         Stack<STACK_LDS, BLOCK>& st, uint32_t* hit_tri, uint32_t* hit_front, Visits* vis) {
+    V3 inv = v3(recip(d.x), recip(d.y), recip(d.z));
+    bool have = false;
+    uint32_t cur = root_ref;
+    st.sp = 0;
+    for (;;) {
+        if (cur & LEAF_BIT) {
+            uint32_t k = cur & ~LEAF_BIT;
+            uint32_t last;
+            do {
+                const float4* tp = sc.tris + (size_t)k * 3;
+                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                if (COUNT) vis->n_tri += 1;
+                float t, det;
+                if (tri_hit(v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), o, d, t_min, t_max,
+                            &t, &det)) {
+                    *hit_tri = k;
+                    *hit_front = det > 0.0f;
+                    if (ANY) return true;
+                    t_max = t;
+                    have = true;
+                }
+                last = __float_as_uint(q1.w);
+                ++k;
+            } while (!last);
+            if (st.sp == 0) break;
+            cur = st.pop();
+        } else {
+            const DPair* pp = sc.pairs + cur;
+            const float4* raw = reinterpret_cast<const float4*>(pp);
+            float4 a0 = raw[0], a1 = raw[1], b0 = raw[2], b1 = raw[3];
+            if (COUNT) vis->n_int += 1;
+            float lo1[3] = {a0.x, a0.y, a0.z}, hi1[3] = {a0.w, a1.x, a1.y};
+            float lo2[3] = {b0.x, b0.y, b0.z}, hi2[3] = {b0.w, b1.x, b1.y};
+            uint32_t ref1 = __float_as_uint(a1.z), ref2 = __float_as_uint(b1.z);
+            float t1, t2;
+            bool h1 = aabb_hit(lo1, hi1, o, inv, t_min, t_max, &t1);
+            bool h2 = aabb_hit(lo2, hi2, o, inv, t_min, t_max, &t2);
+            if (h1 && h2) {
+                bool swap = t1 > t2;
+                st.push(swap ? ref1 : ref2);
+                cur = swap ? ref2 : ref1;
+            } else if (h1) {
+                cur = ref1;
+            } else if (h2) {
+                cur = ref2;
+            } else {
+                if (st.sp == 0) break;
+                cur = st.pop();
+            }
+        }
+    }
+    return have;
+}
+
+// Sphere::hit (primitives.rs:70-94 with make_intersection :49-66)
+RT_DEV bool sphere_hit(V3 center, float radius, V3 o, V3 d, float t_min, float t_max, float* t_out, V3* n_out,
+                       uint32_t* ff_out) {
+    V3 r_oc = o - center;
+    float a = norm_squared(d);
+    float half_b = dot(d, r_oc);
+    float c = norm_squared(r_oc) - radius * radius;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return false;
+    float sqrt_d = sqrtf(disc);
+    float t = (-(half_b + sqrt_d)) / a;
+    if (!(t > t_min && t < t_max)) {
+        t = (-half_b + sqrt_d) / a;
+        if (!(t > t_min && t < t_max)) return false;
+    }
+    V3 n = ((o + d * t) - center) / radius;
+    *t_out = t;
+    *n_out = n;
+    *ff_out = dot(d, n) < 0.0f;
+    return true;
+}
+
+// Plane::hit (primitives.rs:229-247); front_face = denom > 0 (the reference's sense, kept)
+RT_DEV bool plane_hit(V3 normal, float dd, V3 o, V3 d, float t_min, float t_max, float* t_out, uint32_t* ff_out) {
+    float denom = dot(normal, d);
+    if (fabsf(denom) <= F32_EPSILON) return false;
+    float t = -(dot(normal, o) + dd) / denom;
+    if (t < t_max && t > t_min) {
+        *t_out = t;
+        *ff_out = denom > 0.0f;
+        return true;
+    }
+    return false;
+}
+
+// Surface::hit of one object in OBJECT space; Nearest mode.
+template <bool COUNT, int STACK_LDS, int BLOCK>
+RT_DEV bool surface_hit(const DScene& sc, const DObject& ob, V3 o, V3 d, float t_min, float t_max,
+                        Stack<STACK_LDS, BLOCK>& st, float* t_out, V3* n_out, uint32_t* ff_out, uint32_t* prim_out,
+                        Visits* vis) {
+    switch (ob.kind) {
+        case RT_SURF_MESH: {
+            uint32_t tri = 0, ff = 0;
+            float tm = t_max;
+            if (!traverse_bvh<false, COUNT, STACK_LDS, BLOCK>(sc, ob.root_ref, o, d, t_min, tm, st, &tri, &ff, vis))
+                return false;
+            const float4* tp = sc.tris + (size_t)tri * 3;
+            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            *t_out = tm;
+            *n_out = normalise(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));  // primitives.rs:175
+            *ff_out = ff;
+            *prim_out = __float_as_uint(q0.w);
+            return true;
+        }
+        case RT_SURF_SPHERE:
+            *prim_out = 0;
+            return sphere_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), ob.surf[3], o, d, t_min, t_max, t_out, n_out,
+                              ff_out);
+        case RT_SURF_PLANE:
+            *prim_out = 0;
+            *n_out = v3(ob.surf[0], ob.surf[1], ob.surf[2]);
+            return plane_hit(*n_out, ob.surf[3], o, d, t_min, t_max, t_out, ff_out);
+        case RT_SURF_TRIANGLE: {
+            V3 e1 = v3(ob.surf[3], ob.surf[4], ob.surf[5]), e2 = v3(ob.surf[6], ob.surf[7], ob.surf[8]);
+            float t, det;
+            if (!tri_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), e1, e2, o, d, t_min, t_max, &t, &det)) return false;
+            *t_out = t;
+            *n_out = normalise(cross(e1, e2));
+            *ff_out = det > 0.0f;
+            *prim_out = 0;
+            return true;
+        }
+        default:
+            return false;  // Point (primitives.rs:19-23)
+    }
+}
+
+// Engine::hit (path_integrator.rs:88-97) over Object::hit (object.rs:32-68).
+template <bool COUNT, int STACK_LDS, int BLOCK>
+RT_DEV bool scene_hit(const DScene& sc, V3 o, V3 d, float t_min, float t_max, Stack<STACK_LDS, BLOCK>& st, Hit* hit,
+                      Visits* vis) {
+    bool result = false;
+    for (uint32_t i = 0; i < sc.n_objects; ++i) {
+        const DObject& ob = sc.objects[i];
+        float t;
+        V3 n;
+        uint32_t ff, prim;
+        bool h;
+        if (!ob.has_transform) {
+            h = surface_hit<COUNT, STACK_LDS, BLOCK>(sc, ob, o, d, t_min, t_max, st, &t, &n, &ff, &prim, vis);
+        } else {
+            V3 oo = mat_mul(ob.inv_m, o) + v3(ob.inv_t[0], ob.inv_t[1], ob.inv_t[2]);
+            V3 dd = mat_mul(ob.inv_m, d);
+            float nr = norm_recip(dd);
+            h = surface_hit<COUNT, STACK_LDS, BLOCK>(sc, ob, oo, dd * nr, t_min, t_max, st, &t, &n, &ff, &prim, vis);
+            if (h) {
+                t = t * nr;
+                n = normalise(mat_transpose_mul(ob.inv_m, n));
+            }
+        }
+        if (h) {
+            t_max = t;
+            hit->t = t;
+            hit->normal = n;
+            hit->front_face = ff;
+            hit->prim = prim;
+            hit->obj = i;
+            result = true;
+        }
+    }
+    return result;
+}
+
+// Engine::hit_bool (path_integrator.rs:100-104) over Object::hit_bool (object.rs:71-87).
+template <bool COUNT, int STACK_LDS, int BLOCK>
+RT_DEV bool scene_hit_bool(const DScene& sc, V3 o, V3 d, float t_min, float t_max, Stack<STACK_LDS, BLOCK>& st,
+                           Visits* vis) {
+    for (uint32_t i = 0; i < sc.n_objects; ++i) {
+        const DObject& ob = sc.objects[i];
+        V3 oo = o, dd = d;
+        if (ob.has_transform) {
+            oo = mat_mul(ob.inv_m, o) + v3(ob.inv_t[0], ob.inv_t[1], ob.inv_t[2]);
+            dd = mat_mul(ob.inv_m, d);
+            dd = dd * norm_recip(dd);
+        }
+        bool h;
+        if (ob.kind == RT_SURF_MESH) {
+            uint32_t tri, ff;
+            float tm = t_max;
+            h = traverse_bvh<true, COUNT, STACK_LDS, BLOCK>(sc, ob.root_ref, oo, dd, t_min, tm, st, &tri, &ff, vis);
+        } else {
+            float t;
+            V3 n;
+            uint32_t ff, prim;
+            h = surface_hit<COUNT, STACK_LDS, BLOCK>(sc, ob, oo, dd, t_min, t_max, st, &t, &n, &ff, &prim, vis);
+        }
+        if (h) return true;
+    }
+    return false;
+}
+
+}  // namespace rtd

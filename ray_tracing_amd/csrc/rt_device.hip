@@ -1,0 +1,523 @@
+// Device context, scene upload and the batch intersector entry points (rt_trace_closest /
+// rt_trace_any).  gfx950 only; compiled with -ffp-contract=off (see device_math.h).
+#include <cmath>
+#include <cstring>
+
+#include "context.h"
+#include "host/hostmath.h"
+
+using namespace rtd;
+
+// ---------------------------------------------------------------- buffers
+int DevBuf::ensure(size_t need) {
+    if (need <= bytes) return RT_OK;
+    if (p) {
+        RT_HIP(hipFree(p));
+        p = nullptr;
+        bytes = 0;
+    }
+    size_t cap = need + need / 8 + 256;
+    RT_HIP(hipMalloc(&p, cap));
+    bytes = cap;
+    return RT_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes) {
+    if (ctx->overflow_levels == 0) return RT_OK;
+    return ctx->overflow.ensure(lanes * ctx->overflow_levels * sizeof(uint32_t));
+}
+
+// ---------------------------------------------------------------- kernels
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DScene sc, rt_rays rays, size_t n, float t_min,
+                                                            float t_max, rt_hits out, uint32_t* overflow,
+                                                            uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const size_t gtid = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    const size_t total = (size_t)gridDim.x * RT_BLOCK;
+    Stack<RT_STACK_LDS, RT_BLOCK> st;
+    st.lds = lds_stack + threadIdx.x;
+    st.overflow = overflow + gtid;
+    st.overflow_stride = overflow_stride;
+    st.sp = 0;
+    for (size_t i = gtid; i < n; i += total) {
+        V3 o = v3(rays.ox[i], rays.oy[i], rays.oz[i]);
+        V3 d = v3(rays.dx[i], rays.dy[i], rays.dz[i]);
+        Hit h;
+        Visits vis = {0, 0};
+        bool got = scene_hit<COUNT, RT_STACK_LDS, RT_BLOCK>(sc, o, d, t_min, t_max, st, &h, &vis);
+        out.t[i] = got ? h.t : __builtin_inff();
+        if (out.prim) out.prim[i] = got ? h.prim : RT_MISS;
+        if (out.obj) out.obj[i] = got ? h.obj : RT_MISS;
+        if (out.nx) out.nx[i] = got ? h.normal.x : 0.0f;
+        if (out.ny) out.ny[i] = got ? h.normal.y : 0.0f;
+        if (out.nz) out.nz[i] = got ? h.normal.z : 0.0f;
+        if (out.front_face) out.front_face[i] = got ? (uint8_t)h.front_face : (uint8_t)0;
+        if (COUNT) {
+            if (out.n_int) out.n_int[i] = vis.n_int;
+            if (out.n_tri) out.n_tri[i] = vis.n_tri;
+        }
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DScene sc, rt_rays rays, size_t n, float t_min, float t_max,
+                                                        uint8_t* occluded, uint32_t* n_int, uint32_t* n_tri,
+                                                        uint32_t* overflow, uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const size_t gtid = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    const size_t total = (size_t)gridDim.x * RT_BLOCK;
+    Stack<RT_STACK_LDS, RT_BLOCK> st;
+    st.lds = lds_stack + threadIdx.x;
+    st.overflow = overflow + gtid;
+    st.overflow_stride = overflow_stride;
+    st.sp = 0;
+    for (size_t i = gtid; i < n; i += total) {
+        V3 o = v3(rays.ox[i], rays.oy[i], rays.oz[i]);
+        V3 d = v3(rays.dx[i], rays.dy[i], rays.dz[i]);
+        Visits vis = {0, 0};
+        bool got = scene_hit_bool<COUNT, RT_STACK_LDS, RT_BLOCK>(sc, o, d, t_min, t_max, st, &vis);
+        occluded[i] = got ? 1 : 0;
+        if (COUNT) {
+            if (n_int) n_int[i] = vis.n_int;
+            if (n_tri) n_tri[i] = vis.n_tri;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- helpers
+namespace {
+
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory: not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+struct Stager {  // stages host arrays through device buffers of the context
+    rt_ctx* ctx;
+    int next = 0;
+    struct Back {
+        void* host;
+        void* dev;
+        size_t bytes;
+    };
+    std::vector<Back> backs;
+    int in(const void* src, size_t bytes, const void** dev) {
+        if (!src) {
+            *dev = nullptr;
+            return RT_OK;
+        }
+        if (is_device_ptr(src)) {
+            *dev = src;
+            return RT_OK;
+        }
+        DevBuf& b = ctx->staging[next++];
+        int rc = b.ensure(bytes);
+        if (rc != RT_OK) return rc;
+        RT_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        *dev = b.p;
+        return RT_OK;
+    }
+    int out(void* dst, size_t bytes, void** dev) {
+        if (!dst) {
+            *dev = nullptr;
+            return RT_OK;
+        }
+        if (is_device_ptr(dst)) {
+            *dev = dst;
+            return RT_OK;
+        }
+        DevBuf& b = ctx->staging[next++];
+        int rc = b.ensure(bytes);
+        if (rc != RT_OK) return rc;
+        *dev = b.p;
+        backs.push_back({dst, b.p, bytes});
+        return RT_OK;
+    }
+    int finish() {
+        for (const Back& b : backs)
+            RT_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
+};
+
+int check_ctx(rt_ctx* ctx, bool need_scene) {
+    if (!ctx) {
+        rth::set_error("null context");
+        return RT_ERR_INVALID;
+    }
+    if (need_scene && !ctx->has_scene) {
+        rth::set_error("no scene uploaded (call rt_upload_scene first)");
+        return RT_ERR_STATE;
+    }
+    RT_HIP(hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+int trace_grid(size_t n) {
+    size_t blocks = (n + RT_BLOCK - 1) / RT_BLOCK;
+    if (blocks > (size_t)RT_TRACE_GRID) blocks = RT_TRACE_GRID;
+    if (blocks == 0) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- C ABI
+extern "C" {
+
+int rt_create(int device, rt_ctx** out) {
+    if (!out) {
+        rth::set_error("rt_create: null out");
+        return RT_ERR_INVALID;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        rth::set_error("rt_create: no HIP device available (%s)", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    if (device < 0 || device >= count) {
+        rth::set_error("rt_create: device %d out of range (%d devices)", device, count);
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipSetDevice(device));
+    rt_ctx* ctx = new rt_ctx;
+    ctx->device = device;
+    RT_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    RT_HIP(hipEventCreate(&ctx->ev[0]));
+    RT_HIP(hipEventCreate(&ctx->ev[1]));
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->pairs, &ctx->tris, &ctx->objects, &ctx->materials, &ctx->lights, &ctx->media,
+                      &ctx->overflow, &ctx->path_state, &ctx->queues, &ctx->counters, &ctx->sample_sum};
+    for (DevBuf* b : bufs) b->release();
+    for (DevBuf& b : ctx->staging) b.release();
+    if (ctx->ev[0]) (void)hipEventDestroy(ctx->ev[0]);
+    if (ctx->ev[1]) (void)hipEventDestroy(ctx->ev[1]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void* rt_stream(rt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
+    int rc = check_ctx(ctx, false);
+    if (rc != RT_OK) return rc;
+    if (!s) {
+        rth::set_error("rt_upload_scene: null scene");
+        return RT_ERR_INVALID;
+    }
+    ctx->has_scene = false;
+
+    // ---- BVHs: validate every mesh tree on the host (a malformed tree must never reach a kernel),
+    //      measure its depth, and re-lay it out as aligned child pairs.
+    std::vector<DPair> pairs;
+    std::vector<float4> tris((size_t)s->n_tris * 3);
+    std::vector<uint32_t> root_ref(s->n_bvhs);
+    uint32_t stack_need = 0;
+    for (uint32_t t = 0; t < s->n_tris; ++t) {
+        const float *a = s->tri_v0 + 3 * (size_t)t, *b = s->tri_v1 + 3 * (size_t)t, *c = s->tri_v2 + 3 * (size_t)t;
+        float4 q0, q1, q2;
+        q0.x = a[0]; q0.y = a[1]; q0.z = a[2];
+        uint32_t pid = s->tri_prim_id[t];
+        memcpy(&q0.w, &pid, 4);
+        q1.x = b[0] - a[0]; q1.y = b[1] - a[1]; q1.z = b[2] - a[2]; q1.w = 0.0f;  // e1 (primitives.rs:147)
+        q2.x = c[0] - a[0]; q2.y = c[1] - a[1]; q2.z = c[2] - a[2]; q2.w = 0.0f;  // e2 (primitives.rs:148)
+        tris[3 * (size_t)t] = q0;
+        tris[3 * (size_t)t + 1] = q1;
+        tris[3 * (size_t)t + 2] = q2;
+    }
+    for (uint32_t bi = 0; bi < s->n_bvhs; ++bi) {
+        const rt_bvh_flat& b = s->bvhs[bi];
+        if (b.node_count == 0 || (uint64_t)b.node_offset + b.node_count > s->n_nodes ||
+            (uint64_t)b.tri_offset + b.tri_count > s->n_tris || b.tri_count == 0) {
+            rth::set_error("rt_upload_scene: bvh %u: ranges outside the node/triangle arrays", bi);
+            return RT_ERR_INVALID;
+        }
+        const uint32_t* nidx = s->node_index + b.node_offset;
+        const uint32_t* nnp = s->node_num_prim + b.node_offset;
+        std::vector<uint32_t> pair_id(b.node_count, 0xFFFFFFFFu);
+        uint32_t pair_base = (uint32_t)pairs.size(), n_internal = 0;
+        for (uint32_t k = 0; k < b.node_count; ++k)
+            if (nnp[k] == 0) pair_id[k] = pair_base + n_internal++;
+        if ((uint64_t)pair_base + n_internal >= LEAF_BIT) {
+            rth::set_error("rt_upload_scene: more than 2^31 internal nodes");
+            return RT_ERR_LIMIT;
+        }
+        pairs.resize((size_t)pair_base + n_internal);
+        auto ref_of = [&](uint32_t k) -> uint32_t {
+            return nnp[k] > 0 ? (LEAF_BIT | (b.tri_offset + nidx[k])) : pair_id[k];
+        };
+        // walk from the root: every node reached exactly once, children in range, leaves in range
+        std::vector<uint8_t> seen(b.node_count, 0);
+        std::vector<std::pair<uint32_t, uint32_t>> todo;  // node, depth
+        todo.push_back({0, 0});
+        uint32_t depth_max = 0;
+        while (!todo.empty()) {
+            auto [k, depth] = todo.back();
+            todo.pop_back();
+            if (seen[k]) {
+                rth::set_error("rt_upload_scene: bvh %u: node %u reachable twice (not a tree)", bi, k);
+                return RT_ERR_INVALID;
+            }
+            seen[k] = 1;
+            if (depth > depth_max) depth_max = depth;
+            if (nnp[k] > 0) {
+                if ((uint64_t)nidx[k] + nnp[k] > b.tri_count) {
+                    rth::set_error("rt_upload_scene: bvh %u: leaf %u outside the triangle range", bi, k);
+                    return RT_ERR_INVALID;
+                }
+                uint32_t last = b.tri_offset + nidx[k] + nnp[k] - 1;
+                uint32_t one = 1;
+                memcpy(&tris[3 * (size_t)last + 1].w, &one, 4);  // last-in-leaf flag
+                continue;
+            }
+            uint32_t c0 = nidx[k];
+            if (c0 == 0 || (uint64_t)c0 + 1 >= b.node_count) {
+                rth::set_error("rt_upload_scene: bvh %u: node %u has children out of range", bi, k);
+                return RT_ERR_INVALID;
+            }
+            DPair& p = pairs[pair_id[k]];
+            for (int c = 0; c < 2; ++c) {
+                uint32_t ck = c0 + c;
+                const float* up = s->node_upper + 3 * (size_t)(b.node_offset + ck);
+                const float* lw = s->node_lower + 3 * (size_t)(b.node_offset + ck);
+                for (int a = 0; a < 3; ++a) {
+                    p.c[c].lo[a] = lw[a];
+                    p.c[c].hi[a] = up[a];
+                }
+                p.c[c].ref = ref_of(ck);
+                p.c[c].num_prim = nnp[ck];
+                todo.push_back({ck, depth + 1});
+            }
+        }
+        root_ref[bi] = ref_of(0);
+        if (depth_max > stack_need) stack_need = depth_max;
+    }
+
+    // ---- objects
+    std::vector<DObject> objs(s->n_objects);
+    for (uint32_t i = 0; i < s->n_objects; ++i) {
+        const rt_object_flat& f = s->objects[i];
+        DObject& o = objs[i];
+        memset(&o, 0, sizeof o);
+        o.kind = f.surface_kind;
+        if (f.surface_kind > RT_SURF_POINT) {
+            rth::set_error("rt_upload_scene: object %u: unknown surface kind", i);
+            return RT_ERR_INVALID;
+        }
+        if (f.surface_kind == RT_SURF_MESH) {
+            if (f.bvh >= s->n_bvhs) {
+                rth::set_error("rt_upload_scene: object %u: bvh index out of range", i);
+                return RT_ERR_INVALID;
+            }
+            o.root_ref = root_ref[f.bvh];
+        }
+        memcpy(o.surf, f.surf, 9 * sizeof(float));
+        if (f.surface_kind == RT_SURF_TRIANGLE) {
+            for (int a = 0; a < 3; ++a) {
+                o.surf[3 + a] = f.surf[3 + a] - f.surf[a];
+                o.surf[6 + a] = f.surf[6 + a] - f.surf[a];
+            }
+        }
+        o.has_transform = f.has_transform;
+        memcpy(o.inv_m, f.inv_matrix, sizeof o.inv_m);
+        memcpy(o.inv_t, f.inv_translation, sizeof o.inv_t);
+        if (f.material >= s->n_materials || f.medium_inside >= (int32_t)s->n_media ||
+            f.medium_outside >= (int32_t)s->n_media) {
+            rth::set_error("rt_upload_scene: object %u: material/medium index out of range", i);
+            return RT_ERR_INVALID;
+        }
+        o.material = f.material;
+        o.has_medium_interface = f.has_medium_interface;
+        o.medium_inside = f.medium_inside;
+        o.medium_outside = f.medium_outside;
+    }
+    if (s->initial_medium >= (int32_t)s->n_media || s->initial_medium < RT_MEDIUM_AUTO) {
+        rth::set_error("rt_upload_scene: initial_medium out of range");
+        return RT_ERR_INVALID;
+    }
+
+    // ---- copy
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        int r = b.ensure(bytes ? bytes : 64);
+        if (r != RT_OK) return r;
+        if (bytes) RT_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return RT_OK;
+    };
+    if ((rc = up(ctx->pairs, pairs.data(), pairs.size() * sizeof(DPair))) != RT_OK) return rc;
+    if ((rc = up(ctx->tris, tris.data(), tris.size() * sizeof(float4))) != RT_OK) return rc;
+    if ((rc = up(ctx->objects, objs.data(), objs.size() * sizeof(DObject))) != RT_OK) return rc;
+    if ((rc = up(ctx->materials, s->materials, s->n_materials * sizeof(rt_material))) != RT_OK) return rc;
+    if ((rc = up(ctx->lights, s->lights, s->n_lights * sizeof(rt_light))) != RT_OK) return rc;
+    if ((rc = up(ctx->media, s->media, s->n_media * sizeof(rt_medium))) != RT_OK) return rc;
+    RT_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
+
+    DScene& d = ctx->scene;
+    d.pairs = (const DPair*)ctx->pairs.p;
+    d.tris = (const float4*)ctx->tris.p;
+    d.objects = (const DObject*)ctx->objects.p;
+    d.materials = (const rt_material*)ctx->materials.p;
+    d.lights = (const rt_light*)ctx->lights.p;
+    d.media = (const rt_medium*)ctx->media.p;
+    d.n_objects = s->n_objects;
+    d.n_lights = s->n_lights;
+    d.n_media = s->n_media;
+    d.n_materials = s->n_materials;
+    d.camera = s->camera;
+    d.initial_medium = s->initial_medium == RT_MEDIUM_AUTO ? RT_MEDIUM_NONE : s->initial_medium;
+    d.stack_need = stack_need;
+    ctx->overflow_levels = stack_need > (uint32_t)RT_STACK_LDS ? stack_need - RT_STACK_LDS : 0;
+    ctx->has_scene = true;
+
+    if (s->initial_medium == RT_MEDIUM_AUTO) {
+        // Engine::set_initial_medium (path_integrator.rs:65-85) with the device intersector:
+        // walk camera.ray(0.5, 0.5) from hit to hit, counting medium-interface entries and exits.
+        const rt_camera_flat& c = s->camera;
+        rth::V3 origin = rth::v3(c.origin[0], c.origin[1], c.origin[2]);
+        rth::V3 llc = rth::v3(c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2]);
+        rth::V3 hor = rth::v3(c.horizontal[0], c.horizontal[1], c.horizontal[2]);
+        rth::V3 ver = rth::v3(c.vertical[0], c.vertical[1], c.vertical[2]);
+        rth::V3 dir = rth::normalise(llc + 0.5f * hor + 0.5f * ver - origin, nullptr);  // camera.rs:60-63
+        int32_t depth = 0;
+        for (int guard = 0; guard < 100000; ++guard) {
+            float ox = origin.x, oy = origin.y, oz = origin.z, dx = dir.x, dy = dir.y, dz = dir.z;
+            rt_rays rays = {&ox, &oy, &oz, &dx, &dy, &dz};
+            float t;
+            uint32_t obj;
+            uint8_t ff;
+            rt_hits hits;
+            memset(&hits, 0, sizeof hits);
+            hits.t = &t;
+            hits.obj = &obj;
+            hits.front_face = &ff;
+            rc = rt_trace_closest(ctx, &rays, 1, 1e-3f, INFINITY, &hits);
+            if (rc != RT_OK) {
+                ctx->has_scene = false;
+                return rc;
+            }
+            if (obj == RT_MISS) break;
+            const rt_object_flat& o = s->objects[obj];
+            bool entering = ff != 0;
+            if (o.has_medium_interface) {
+                if (!entering && depth == 0) {
+                    d.initial_medium = o.medium_outside;
+                    break;
+                }
+                depth += entering ? 1 : -1;
+            }
+            origin = origin + dir * t;  // ray.origin = ray.at(intr.t)
+        }
+    }
+    return RT_OK;
+}
+
+int rt_initial_medium(const rt_ctx* ctx, int32_t* out) {
+    if (!ctx || !out || !ctx->has_scene) {
+        rth::set_error("rt_initial_medium: no scene");
+        return RT_ERR_STATE;
+    }
+    *out = ctx->scene.initial_medium;
+    return RT_OK;
+}
+
+int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, const rt_hits* hits) {
+    int rc = check_ctx(ctx, true);
+    if (rc != RT_OK) return rc;
+    if (!rays || !hits || !hits->t || !rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz) {
+        rth::set_error("rt_trace_closest: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (n == 0) return RT_OK;
+    Stager sg{ctx};
+    rt_rays dr;
+    rt_hits dh;
+    const size_t fb = n * sizeof(float);
+    if ((rc = sg.in(rays->ox, fb, (const void**)&dr.ox)) || (rc = sg.in(rays->oy, fb, (const void**)&dr.oy)) ||
+        (rc = sg.in(rays->oz, fb, (const void**)&dr.oz)) || (rc = sg.in(rays->dx, fb, (const void**)&dr.dx)) ||
+        (rc = sg.in(rays->dy, fb, (const void**)&dr.dy)) || (rc = sg.in(rays->dz, fb, (const void**)&dr.dz)))
+        return rc;
+    if ((rc = sg.out(hits->t, fb, (void**)&dh.t)) || (rc = sg.out(hits->prim, fb, (void**)&dh.prim)) ||
+        (rc = sg.out(hits->obj, fb, (void**)&dh.obj)) || (rc = sg.out(hits->nx, fb, (void**)&dh.nx)) ||
+        (rc = sg.out(hits->ny, fb, (void**)&dh.ny)) || (rc = sg.out(hits->nz, fb, (void**)&dh.nz)) ||
+        (rc = sg.out(hits->front_face, n, (void**)&dh.front_face)) ||
+        (rc = sg.out(hits->n_int, fb, (void**)&dh.n_int)) || (rc = sg.out(hits->n_tri, fb, (void**)&dh.n_tri)))
+        return rc;
+    int grid = trace_grid(n);
+    size_t lanes = (size_t)grid * RT_BLOCK;
+    if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
+    bool count = dh.n_int || dh.n_tri;
+    if (count)
+        hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n,
+                           t_min, t_max, dh, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
+    else
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n,
+                           t_min, t_max, dh, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
+    RT_HIP(hipGetLastError());
+    return sg.finish();
+}
+
+int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, uint8_t* occluded,
+                 uint32_t* n_int, uint32_t* n_tri) {
+    int rc = check_ctx(ctx, true);
+    if (rc != RT_OK) return rc;
+    if (!rays || !occluded || !rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz) {
+        rth::set_error("rt_trace_any: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (n == 0) return RT_OK;
+    Stager sg{ctx};
+    rt_rays dr;
+    uint8_t* d_occ;
+    uint32_t *d_ni, *d_nt;
+    const size_t fb = n * sizeof(float);
+    if ((rc = sg.in(rays->ox, fb, (const void**)&dr.ox)) || (rc = sg.in(rays->oy, fb, (const void**)&dr.oy)) ||
+        (rc = sg.in(rays->oz, fb, (const void**)&dr.oz)) || (rc = sg.in(rays->dx, fb, (const void**)&dr.dx)) ||
+        (rc = sg.in(rays->dy, fb, (const void**)&dr.dy)) || (rc = sg.in(rays->dz, fb, (const void**)&dr.dz)))
+        return rc;
+    if ((rc = sg.out(occluded, n, (void**)&d_occ)) || (rc = sg.out(n_int, fb, (void**)&d_ni)) ||
+        (rc = sg.out(n_tri, fb, (void**)&d_nt)))
+        return rc;
+    int grid = trace_grid(n);
+    size_t lanes = (size_t)grid * RT_BLOCK;
+    if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
+    if (d_ni || d_nt)
+        hipLaunchKernelGGL(k_trace_any<true>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n, t_min,
+                           t_max, d_occ, d_ni, d_nt, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
+    else
+        hipLaunchKernelGGL(k_trace_any<false>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n, t_min,
+                           t_max, d_occ, d_ni, d_nt, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
+    RT_HIP(hipGetLastError());
+    return sg.finish();
+}
+
+int rt_set_max_paths_in_flight(rt_ctx* ctx, uint64_t max_paths) {
+    if (!ctx) {
+        rth::set_error("rt_set_max_paths_in_flight: null context");
+        return RT_ERR_INVALID;
+    }
+    ctx->max_paths_in_flight = max_paths;
+    return RT_OK;
+}
+
+const char* rt_version(void) { return "ray_tracing_amd 0.1 (gfx950)"; }
+
+}  // extern "C"
