@@ -123,6 +123,27 @@ EXPORTS = ["rt_mesh_create", "rt_mesh_read_stl", "rt_mesh_loop_subdivide", "rt_m
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: build it with `make -C ray_tracing_amd/csrc` "
                       "(or __graft_entry__.build()); there is no fallback path")
+
+
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one
+    process cannot both own the GPU (whichever comes second sees no device), so when torch is
+    installed its runtime is loaded first and librt_amd.so binds to it by SONAME."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        tl = os.path.join(os.path.dirname(spec.origin), "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(tl, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
+_preload_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 lib.rt_last_error.restype = C.c_char_p
 lib.rt_version.restype = C.c_char_p
