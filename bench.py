@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the path-tracing hot path on MI355X (one process per GPU).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload render|trace]
+
+workload "render" (default): BASELINE.json configs[2] -- full path tracing (diffuse/dielectric BSDFs,
+    area-light NEE/MIS, Russian roulette) of the 1M-triangle scene at 1920x1080, 64 spp, depth 16.
+    One step = one frame.  With N GPUs every rank renders its own 64 global sample indices
+    [rank*64, rank*64+64) of the same frame and the radiance accumulators are summed to rank 0 with
+    one RCCL reduce over xGMI (weak scaling: the frame gains samples, per-GPU work is fixed).
+workload "trace": BASELINE.json configs[1] -- primary + shadow rays only, same mesh, 1080p 1 spp.
+    One step = one closest-hit launch over 2 073 600 primary rays + one any-hit launch over the
+    shadow rays of the pixels that hit.
+
+Prints ONE JSON line (rank 0).  `value` = rays traced by all ranks / max-over-ranks wall time, rays
+= Engine::hit + Engine::hit_bool calls.  `roofline` prices the dominant kernel
+(closest-hit traversal) with the algorithmic bytes 48 + 64*N_int + 40*N_tri per ray against 8 TB/s;
+its duration comes from HIP events on the library's own stream.  `cpu_baseline` times the oracle
+(oracle/, the C++ restatement of the reference: "port") on a bounded sample of the same workload on
+this box's host cores.  The oracle is used here only as that baseline/cross-check.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["render", "trace"], default="render")
+    ap.add_argument("--levels", type=int, default=9, help="Loop subdivisions of the tetrahedron (9 = 1 048 576 tris)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=1)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    import ray_tracing_amd as rt
+    from ray_tracing_amd import scenes
+
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    width = args.width
+    height = scenes.image_height(width)
+    t_setup = time.time()
+    if args.workload == "trace":
+        desc = scenes.tetrahedron_scene(levels=args.levels)
+    else:
+        desc = scenes.path_scene(levels=args.levels)
+    scene = rt.Scene(desc)
+    ctx = rt.Context(local_rank)
+    ctx.upload(scene)
+    setup_s = time.time() - t_setup
+    n_tris = scene.flat.n_tris
+
+    result = {}
+    if args.workload == "trace":
+        org, dr = scenes.pixel_center_rays(scene.flat.camera, width, height)
+        n = len(org)
+        cols = [torch.from_numpy(np.ascontiguousarray(a[:, k])).to(dev) for a in (org, dr) for k in range(3)]
+        t = torch.empty(n, dtype=torch.float32, device=dev)
+        prim = torch.empty(n, dtype=torch.int32, device=dev)
+        obj = torch.empty(n, dtype=torch.int32, device=dev)
+        ni = torch.zeros(n, dtype=torch.int32, device=dev)
+        nt = torch.zeros(n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        rays6 = [c.data_ptr() for c in cols]
+        hp = dict(t=t.data_ptr(), prim=prim.data_ptr(), obj=obj.data_ptr())
+        # untimed counting pass: visit counters for the algorithmic-bytes figure + shadow-ray set-up
+        ctx.trace_closest_device(rays6, n, dict(hp, n_int=ni.data_ptr(), n_tri=nt.data_ptr()))
+        n_int_total, n_tri_total = int(ni.sum().item()), int(nt.sum().item())
+        hit = obj != -1
+        O = torch.stack(cols[:3], 1)
+        D = torch.stack(cols[3:], 1)
+        P = (O[hit] + D[hit] * t[hit, None])
+        lp = torch.tensor(list(desc.lights[0].pos), dtype=torch.float32, device=dev)
+        L = lp - P
+        L = L / torch.sqrt((L * L).sum(1, keepdim=True))
+        scols = [P[:, k].contiguous() for k in range(3)] + [L[:, k].contiguous() for k in range(3)]
+        ns = len(P)
+        occ = torch.empty(ns, dtype=torch.uint8, device=dev)
+        srays6 = [c.data_ptr() for c in scols]
+        torch.cuda.synchronize()
+        rays_per_step = n + ns
+        closest_ms, any_ms = [], []
+
+        def step(record):
+            ctx.trace_closest_device(rays6, n, hp)
+            if record:
+                closest_ms.append(ctx.last_kernel_ms())
+            ctx.trace_any_device(srays6, ns, occ.data_ptr())
+            if record:
+                any_ms.append(ctx.last_kernel_ms())
+
+        for _ in range(args.warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        alg_bytes = 48 * n + 64 * n_int_total + 40 * n_tri_total
+        kern_ms = float(np.mean(closest_ms))
+        result.update(kernel="k_trace_closest", kernel_ms=kern_ms, any_ms=float(np.mean(any_ms)),
+                      alg_bytes=alg_bytes, n_int_mean=n_int_total / n, n_tri_mean=n_tri_total / n,
+                      rays_closest=n, rays_shadow=ns)
+        workload = f"configs[1]: primary+shadow rays, {n_tris}-triangle subdivided tetrahedron, {width}x{height}, 1 spp"
+    else:
+        acc = torch.zeros(height, width, 3, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        spp_first = rank * args.spp
+        # untimed counting pass (also the warm-up of every kernel)
+        _, st_count = ctx.render(width, height, args.spp, args.depth, args.seed, spp_first,
+                                 flags=rt.api.RENDER_COUNT_VISITS, out=acc.data_ptr())
+        last = {}
+
+        def step(record):
+            _, st = ctx.render(width, height, args.spp, args.depth, args.seed, spp_first,
+                               flags=rt.api.RENDER_TIME_STAGES if record else 0, out=acc.data_ptr())
+            if world > 1:
+                dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
+            last["st"] = st
+
+        for _ in range(args.warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # one more (untimed) step with per-stage HIP events for the roofline figure
+        step(True)
+        st = last["st"]
+        rays_per_step = st.rays_closest + st.rays_shadow
+        alg_bytes_total = 48 * st_count.rays_closest + 64 * st_count.nodes_visited + 40 * st_count.tris_tested
+        launches = max(1, st.launches_extend)
+        result.update(kernel="k_extend", kernel_ms=st.ms_extend / launches, alg_bytes=alg_bytes_total / launches,
+                      launches=int(launches), ms_extend=st.ms_extend, ms_shadow=st.ms_shadow, ms_shade=st.ms_shade,
+                      ms_generate=st.ms_generate, ms_compact=st.ms_compact, ms_device_total=st.ms_total,
+                      n_int_mean=st_count.nodes_visited / max(1, st_count.rays_closest),
+                      n_tri_mean=st_count.tris_tested / max(1, st_count.rays_closest),
+                      rays_closest=int(st.rays_closest), rays_shadow=int(st.rays_shadow),
+                      iterations=int(st.iterations))
+        workload = (f"configs[2]: path tracing diffuse+dielectric, area-light NEE/MIS, RR, {n_tris} triangles, "
+                    f"{width}x{height}, {args.spp} spp, depth {args.depth}")
+
+    # max over ranks of the timed region
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([float(rays_per_step)], dtype=torch.float64, device=dev)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        total_rays_per_step = float(rr.item())
+    else:
+        total_rays_per_step = float(rays_per_step)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_rays_per_step * args.steps / elapsed / 1e6
+        achieved = result["alg_bytes"] / (result["kernel_ms"] * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (path-segment rays, whole node)", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "seed": args.seed, "parallelism": f"sample-sharded x{world}" if world > 1 else "1 GPU",
+                       "ms_per_frame": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": result["kernel"], "kernel_ms": round(result["kernel_ms"], 4),
+                         "alg_bytes_per_launch": int(result["alg_bytes"]),
+                         "n_int_per_ray": round(result["n_int_mean"], 3), "n_tri_per_ray": round(result["n_tri_mean"], 3)},
+            "detail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in result.items()
+                       if k not in ("kernel", "alg_bytes")},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, desc, scene, width, height)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, desc, scene, width, height):
+    """Oracle (C++ restatement of the reference; the reference itself is Rust and cannot be built
+    here) on a bounded sample of the same workload, on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from ray_tracing_amd import scenes
+    orc = ob.OracleScene(desc)
+    if args.workload == "trace":
+        org, dr = scenes.pixel_center_rays(scene.flat.camera, width, height)
+        rows = np.arange(0, height, 4)
+        idx = (rows[:, None] * width + np.arange(width)[None, :]).ravel()
+        o, d = org[idx], dr[idx]
+        t0 = time.perf_counter()
+        h = orc.trace_closest(o, d)
+        hit = h["obj"] != 0xFFFFFFFF
+        p = (o[hit] + d[hit] * h["t"][hit, None]).astype(np.float32)
+        lp = np.array(desc.lights[0].pos[:], np.float32)
+        l = (lp - p).astype(np.float32)
+        l = (l / np.sqrt((l * l).sum(1, dtype=np.float32))[:, None]).astype(np.float32)
+        orc.trace_any(p, l)
+        dt = time.perf_counter() - t0
+        rays = len(o) + len(p)
+        return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                "sample": f"every 4th image row of the same ray batch ({rays} rays, {dt:.1f} s)"}
+    threads = args.cpu_threads
+    rows = (height // 2, height // 2 + 8)
+    spp = min(args.spp, 8)
+    _, st = orc.render(width, height, spp, args.depth, args.seed, 0, rows=rows, threads=threads)
+    rays = st.rays_closest + st.rays_shadow
+    return {"value": round(rays / st.seconds / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"rows {rows[0]}..{rows[1] - 1} of the same frame at {spp} spp ({rays} rays, {st.seconds:.1f} s)"}
+
+
+if __name__ == "__main__":
+    main()

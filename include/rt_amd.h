@@ -296,6 +296,11 @@ int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp_first, 
 /* Upper bound on camera paths kept in flight by rt_render (default: sized from free HBM). */
 int rt_set_max_paths_in_flight(rt_ctx* ctx, uint64_t max_paths);
 
+/* Device time (ms) of the kernel launched by the most recent rt_trace_closest / rt_trace_any call:
+   HIP events recorded on the context stream directly before and after that one launch (staging
+   copies excluded).  No counterpart in the reference; used by bench.py for the roofline figure. */
+int rt_last_kernel_ms(rt_ctx* ctx, float* ms);
+
 /* The HIP stream the context launches on (a hipStream_t), for callers that time with HIP events. */
 void* rt_stream(rt_ctx* ctx);
 

@@ -118,7 +118,7 @@ EXPORTS = ["rt_mesh_create", "rt_mesh_read_stl", "rt_mesh_loop_subdivide", "rt_m
            "rt_mesh_volume_centroid", "rt_mesh_counts", "rt_mesh_copy_out", "rt_mesh_destroy", "rt_scene_build",
            "rt_scene_view", "rt_scene_destroy", "rt_tonemap_u8", "rt_write_ppm", "rt_create", "rt_destroy",
            "rt_upload_scene", "rt_initial_medium", "rt_trace_closest", "rt_trace_any", "rt_render",
-           "rt_set_max_paths_in_flight", "rt_stream", "rt_last_error", "rt_version"]
+           "rt_set_max_paths_in_flight", "rt_last_kernel_ms", "rt_stream", "rt_last_error", "rt_version"]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: build it with `make -C ray_tracing_amd/csrc` "
@@ -392,6 +392,11 @@ class Context:
     def stream(self):
         return lib.rt_stream(self.handle)
 
+    def last_kernel_ms(self):
+        v = C.c_float()
+        _check(lib.rt_last_kernel_ms(self.handle, C.byref(v)))
+        return v.value
+
     def set_max_paths_in_flight(self, n):
         _check(lib.rt_set_max_paths_in_flight(self.handle, n))
 
@@ -429,9 +434,9 @@ class Context:
         hits = Hits(*[hits_ptrs.get(k) for k, _ in Hits._fields_])
         _check(lib.rt_trace_closest(self.handle, C.byref(rays), n, t_min, t_max, C.byref(hits)))
 
-    def trace_any_device(self, rays6, n, occluded, t_min=1e-3, t_max=np.inf):
+    def trace_any_device(self, rays6, n, occluded, t_min=1e-3, t_max=np.inf, n_int=None, n_tri=None):
         rays = Rays(*rays6)
-        _check(lib.rt_trace_any(self.handle, C.byref(rays), n, t_min, t_max, occluded, None, None))
+        _check(lib.rt_trace_any(self.handle, C.byref(rays), n, t_min, t_max, occluded, n_int, n_tri))
 
     def render(self, width, height, spp, depth, seed=0, spp_first=0, flags=0, out=None):
         """Engine::render without the PPM text. out: optional device/host buffer address or array."""

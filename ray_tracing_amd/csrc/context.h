@@ -44,6 +44,7 @@ struct rt_ctx {
     DevBuf path_state, queues, counters, sample_sum;
     uint64_t max_paths_in_flight = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    float last_kernel_ms = 0.0f;
 };
 
 int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes);

@@ -465,6 +465,7 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
     size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
     bool count = dh.n_int || dh.n_tri;
+    RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (count)
         hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n,
                            t_min, t_max, dh, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
@@ -472,7 +473,10 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
         hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n,
                            t_min, t_max, dh, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
     RT_HIP(hipGetLastError());
-    return sg.finish();
+    RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    if ((rc = sg.finish()) != RT_OK) return rc;
+    RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
+    return RT_OK;
 }
 
 int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, uint8_t* occluded,
@@ -499,6 +503,7 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
     int grid = trace_grid(n);
     size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
+    RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (d_ni || d_nt)
         hipLaunchKernelGGL(k_trace_any<true>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n, t_min,
                            t_max, d_occ, d_ni, d_nt, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
@@ -506,7 +511,10 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
         hipLaunchKernelGGL(k_trace_any<false>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n, t_min,
                            t_max, d_occ, d_ni, d_nt, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
     RT_HIP(hipGetLastError());
-    return sg.finish();
+    RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    if ((rc = sg.finish()) != RT_OK) return rc;
+    RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
+    return RT_OK;
 }
 
 int rt_set_max_paths_in_flight(rt_ctx* ctx, uint64_t max_paths) {
@@ -515,6 +523,15 @@ int rt_set_max_paths_in_flight(rt_ctx* ctx, uint64_t max_paths) {
         return RT_ERR_INVALID;
     }
     ctx->max_paths_in_flight = max_paths;
+    return RT_OK;
+}
+
+int rt_last_kernel_ms(rt_ctx* ctx, float* ms) {
+    if (!ctx || !ms) {
+        rth::set_error("rt_last_kernel_ms: null argument");
+        return RT_ERR_INVALID;
+    }
+    *ms = ctx->last_kernel_ms;
     return RT_OK;
 }
 
