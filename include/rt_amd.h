@@ -272,8 +272,10 @@ typedef struct rt_stats {
     uint64_t rays_closest;  /* Engine::hit calls issued (extend kernel lanes) */
     uint64_t rays_shadow;   /* Engine::hit_bool calls issued (shadow-connect lanes) */
     uint64_t paths;         /* camera paths started = width*height*spp_count */
-    uint64_t nodes_visited; /* sum of n_int over all rays (only if counting was enabled) */
-    uint64_t tris_tested;   /* sum of n_tri over all rays (only if counting was enabled) */
+    uint64_t nodes_visited; /* sum of n_int over the closest-hit rays (only with RT_RENDER_COUNT_VISITS) */
+    uint64_t tris_tested;   /* sum of n_tri over the closest-hit rays (only with RT_RENDER_COUNT_VISITS) */
+    uint64_t nodes_visited_shadow; /* the same two counters for the shadow rays */
+    uint64_t tris_tested_shadow;
     uint32_t iterations;    /* wavefront iterations run (max over batches) */
     uint32_t batches;
     float ms_total;         /* device time of the whole call (HIP events on the context stream) */

@@ -104,7 +104,8 @@ class Hits(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("paths", C.c_uint64),
-                ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("iterations", C.c_uint32),
+                ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("nodes_visited_shadow", C.c_uint64),
+                ("tris_tested_shadow", C.c_uint64), ("iterations", C.c_uint32),
                 ("batches", C.c_uint32), ("ms_total", C.c_float), ("ms_generate", C.c_float),
                 ("ms_extend", C.c_float), ("ms_shade", C.c_float), ("ms_shadow", C.c_float),
                 ("ms_compact", C.c_float), ("launches_extend", C.c_uint64), ("launches_shadow", C.c_uint64)]

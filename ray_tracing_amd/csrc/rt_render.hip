@@ -1,7 +1,662 @@
-// placeholder until the wavefront renderer lands
+// rt_render: Engine::render / Engine::ray_colour (path_integrator.rs:138-318) as a wavefront
+// pipeline on gfx950:
+//
+//   generate        one lane per (pixel, sample): jittered Camera::ray, initial path state
+//   extend          one lane per live path: Engine::hit (closest hit through the BVH)
+//   shade           one lane per live path: one iteration of the `while depth > 0` loop --
+//                   light hit + MIS, medium majorant step, BSDF sample, NEE set-up, throughput,
+//                   medium switch, Russian roulette; leaves alive / shadow flags
+//   compact         wave64 ballot + prefix sums: stable stream compaction of the live-path queue
+//                   and of the shadow-ray queue (block totals come out of shade)
+//   shadow-connect  one lane per shadow ray: Engine::hit_bool, adds the pending NEE term
+//   resolve         per pixel, adds the samples of the batch IN SAMPLE ORDER into the frame sum
+//
+// A path keeps one slot (= sample_in_batch * pixels + pixel) for its whole life; queues hold slot
+// ids.  Radiance additions happen in the reference's order (NEE of iteration k before emission of
+// iteration k+1), and every random draw is addressed by (pixel, sample, bounce, draw), so the sum
+// written for a pixel is bit-identical to the sequential CPU loop.
+#include <cmath>
+#include <cstring>
+
 #include "context.h"
-extern "C" int rt_render(rt_ctx*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t, uint32_t, float*,
-                         rt_stats*) {
-    rth::set_error("rt_render: not built yet");
-    return RT_ERR_STATE;
+#include "device_shade.h"
+
+using namespace rtd;
+
+namespace {
+
+constexpr float T_MIN = 1e-3f;  // path_integrator.rs:15
+constexpr int SHADE_BLOCK = 256;
+
+constexpr uint32_t QF_ALIVE = 1u, QF_SHADOW = 2u;
+constexpr uint32_t PF_PREV_SPECULAR = 1u;
+
+struct PathArrays {      // SoA over slots
+    float4* ray_o;       // origin.xyz, -
+    float4* ray_d;       // direction.xyz, prev_pdf
+    float4* beta;        // throughput.xyz, -
+    float4* rad;         // radiance.xyz, -
+    uint4* meta;         // depth, bounce, current medium (int), flags
+    float4* hit_a;       // t, normal.xyz
+    uint2* hit_b;        // obj | front_face<<31 (RT_MISS = no hit), prim
+    float4* sh_o;        // shadow origin.xyz, -
+    float4* sh_d;        // shadow direction.xyz, -
+    float4* sh_c;        // pending NEE term.xyz, apply flag
+    uint32_t* queue[2];  // live-path queues (ping-pong)
+    uint32_t* shadow_q;
+    uint32_t* qflags;    // per queue position: QF_* of the path there
+    uint32_t* block_cnt; // [2][blocks]: alive, shadow totals per shade block
+    uint32_t* block_off; // [2][blocks]: exclusive scan
+    uint32_t* totals;    // [0] next live count, [1] shadow count
+    unsigned long long* visit; // [0] n_int extend, [1] n_tri extend, [2] n_int shadow, [3] n_tri shadow
+};
+
+struct RenderParams {
+    uint32_t width, height, npix;
+    uint32_t sample_first;  // global index of sample_in_batch 0
+    uint32_t depth;
+    uint32_t k0, k1;        // Philox key = seed
+};
+
+// ---------------------------------------------------------------- generate
+__global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, RenderParams rp, uint32_t n_paths) {
+    uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= n_paths) return;
+    uint32_t pixel = slot % rp.npix, s_local = slot / rp.npix;
+    uint32_t i = pixel % rp.width, j = pixel / rp.width;
+    Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + s_local, 0u, 0u};
+    // path_integrator.rs:303-305
+    float u = ((float)i + rng.f32()) / (float)(rp.width - 1);
+    float v = ((float)j + rng.f32()) / (float)(rp.height - 1);
+    V3 origin = ld3(sc.camera.origin);
+    V3 dir = ld3(sc.camera.lower_left_corner) + u * ld3(sc.camera.horizontal) + v * ld3(sc.camera.vertical) - origin;
+    dir = normalise(dir);  // camera.rs:60-63
+    pa.ray_o[slot] = make_float4(origin.x, origin.y, origin.z, 0.0f);
+    pa.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);  // prev_pdf = 1 (:147)
+    pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    pa.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pa.meta[slot] = make_uint4(rp.depth, 0u, (uint32_t)sc.initial_medium, PF_PREV_SPECULAR);  // :139-148
+    pa.queue[0][slot] = slot;
+}
+
+// ---------------------------------------------------------------- extend
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n,
+                                                     uint32_t* overflow, uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t total = gridDim.x * RT_BLOCK;
+    Stack<RT_STACK_LDS, RT_BLOCK> st;
+    st.lds = lds_stack + threadIdx.x;
+    st.overflow = overflow + gtid;
+    st.overflow_stride = overflow_stride;
+    st.sp = 0;
+    Visits vis = {0, 0};
+    for (uint32_t i = gtid; i < n; i += total) {
+        uint32_t slot = queue[i];
+        float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
+        Hit h;
+        bool got = scene_hit<COUNT, RT_STACK_LDS, RT_BLOCK>(sc, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), T_MIN,
+                                                            __builtin_inff(), st, &h, &vis);
+        if (got) {
+            pa.hit_a[slot] = make_float4(h.t, h.normal.x, h.normal.y, h.normal.z);
+            pa.hit_b[slot] = make_uint2(h.obj | (h.front_face << 31), h.prim);
+        } else {
+            pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
+        }
+    }
+    if (COUNT) {
+        unsigned long long a = vis.n_int, b = vis.n_tri;
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&pa.visit[0], a);
+            atomicAdd(&pa.visit[1], b);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- shadow-connect
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene sc, PathArrays pa, uint32_t n, uint32_t* overflow,
+                                                     uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t total = gridDim.x * RT_BLOCK;
+    Stack<RT_STACK_LDS, RT_BLOCK> st;
+    st.lds = lds_stack + threadIdx.x;
+    st.overflow = overflow + gtid;
+    st.overflow_stride = overflow_stride;
+    st.sp = 0;
+    Visits vis = {0, 0};
+    for (uint32_t i = gtid; i < n; i += total) {
+        uint32_t slot = pa.shadow_q[i];
+        float4 o4 = pa.sh_o[slot], d4 = pa.sh_d[slot];
+        // path_integrator.rs:219: T_MIN..T_MAX, not the light distance
+        bool occluded = scene_hit_bool<COUNT, RT_STACK_LDS, RT_BLOCK>(sc, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z),
+                                                                      T_MIN, __builtin_inff(), st, &vis);
+        if (!occluded) {
+            float4 c = pa.sh_c[slot];
+            if (c.w != 0.0f) {  // p_light > 0 (:234)
+                float4 r = pa.rad[slot];
+                r.x += c.x;
+                r.y += c.y;
+                r.z += c.z;
+                pa.rad[slot] = r;
+            }
+        }
+    }
+    if (COUNT) {
+        unsigned long long a = vis.n_int, b = vis.n_tri;
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&pa.visit[2], a);
+            atomicAdd(&pa.visit[3], b);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- shade
+RT_DEV float mis_weight(float pa, float pb) {  // path_integrator.rs:30-39, power 2
+    float a = pa * pa;
+    float b = pb * pb;
+    if (a + b == 0.0f) return 0.0f;
+    return a / (a + b);
+}
+
+// One iteration of the loop body of ray_colour for the path in `slot`.  Returns QF_* flags.
+RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot) {
+    uint4 meta = pa.meta[slot];
+    uint32_t depth = meta.x, bounce = meta.y;
+    int medium = (int)meta.z;
+    bool prev_specular = (meta.w & PF_PREV_SPECULAR) != 0;
+    float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot], b4 = pa.beta[slot];
+    V3 ro = v3(o4.x, o4.y, o4.z), rd = v3(d4.x, d4.y, d4.z), beta = v3(b4.x, b4.y, b4.z);
+    float prev_pdf = d4.w;
+
+    depth -= 1;  // `while depth > 0 { depth -= 1;` (:150-151)
+    bounce += 1;
+    uint32_t pixel = slot % rp.npix;
+    Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + slot / rp.npix, bounce, 0u};
+
+    uint2 hb = pa.hit_b[slot];
+    bool have_hit = hb.x != RT_MISS;
+    float4 ha = have_hit ? pa.hit_a[slot] : make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+    float t_hit = ha.x;  // T_MAX for a miss (:155)
+    V3 normal = v3(ha.y, ha.z, ha.w);
+
+    // hit_light (:107-121) limited to t_hit
+    {
+        int light = -1;
+        float t_max = t_hit;
+        for (uint32_t l = 0; l < sc.n_lights; ++l) {
+            float t;
+            if (light_hit(sc.lights[l], ro, rd, T_MIN, t_max, &t)) {
+                t_max = t;
+                light = (int)l;
+            }
+        }
+        if (light >= 0) {
+            V3 emitted = ld3(sc.lights[light].intensity);
+            float4 r = pa.rad[slot];
+            V3 add = mul_elemwise(beta, emitted);
+            if (!prev_specular) {
+                float p_light = (1.0f / (float)sc.n_lights) * light_pdf(sc.lights[light], ro, rd);  // :162
+                float w = mis_weight(prev_pdf, p_light);
+                add = w * add;
+            }
+            r.x += add.x;
+            r.y += add.y;
+            r.z += add.z;
+            pa.rad[slot] = r;
+            return 0;  // light terminates the path (:166)
+        }
+    }
+    if (!have_hit) return 0;  // escaped (:170-173)
+
+    // medium step (:177-199)
+    if (medium >= 0) {
+        float transmittance;
+        MediumInteraction mi;
+        int k = medium_sample_interaction(sc.media[medium], ro, rd, t_hit, rng, &transmittance, &mi);
+        if (k == MI_NULL) {
+            beta = beta * transmittance;
+        } else if (k == MI_ABSORPTION) {
+            float4 r = pa.rad[slot];
+            V3 add = mul_elemwise(beta, mi.emission);
+            r.x += add.x;
+            r.y += add.y;
+            r.z += add.z;
+            pa.rad[slot] = r;
+            return 0;
+        } else {
+            depth -= 1;  // u32, wraps at 0 exactly like the release-mode reference (:193)
+            beta = beta * (transmittance * mi.f / mi.pdf);
+            pa.ray_o[slot] = make_float4(mi.origin.x, mi.origin.y, mi.origin.z, 0.0f);
+            pa.ray_d[slot] = make_float4(mi.dir.x, mi.dir.y, mi.dir.z, prev_pdf);
+            pa.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+            pa.meta[slot] = make_uint4(depth, bounce, (uint32_t)medium, meta.w);
+            return depth > 0 ? QF_ALIVE : 0;  // `continue`
+        }
+    }
+
+    const DObject& ob = sc.objects[hb.x & 0x7FFFFFFFu];
+    bool front_face = (hb.x >> 31) != 0;
+    const rt_material& mat = sc.materials[ob.material];
+    V3 interaction_point = ro + rd * t_hit;
+    V3 wo_local = to_shading_coords(-rd, normal);
+
+    BsdfSample bs = bsdf_sample(mat, wo_local, rng);
+    uint32_t flags = 0;
+
+    if (!bs.is_specular) {  // NEE (:210-238); the visibility test is deferred to shadow-connect
+        uint32_t light_index = rng.usize(sc.n_lights);  // sample_lights_uniform (:124-131)
+        float select_light_pdf = 1.0f / (float)sc.n_lights;
+        LightSample ls = light_sample(sc.lights[light_index], interaction_point, rng);
+        V3 wi_local = to_shading_coords(ls.direction, normal);
+        float p_light = ls.pdf * select_light_pdf;
+        V3 bsdf_val = bsdf_eval(mat, wi_local, wo_local);
+        float cosv = fabsf(wi_local.z);
+        V3 contribution = mul_elemwise(ls.spectrum, bsdf_val * cosv);
+        float p_bsdf = bsdf_pdf(mat, wi_local, wo_local);
+        float w = mis_weight(p_light, p_bsdf);
+        V3 add = (w * mul_elemwise(beta, contribution)) / p_light;
+        pa.sh_o[slot] = make_float4(interaction_point.x, interaction_point.y, interaction_point.z, 0.0f);
+        pa.sh_d[slot] = make_float4(ls.direction.x, ls.direction.y, ls.direction.z, 0.0f);
+        pa.sh_c[slot] = make_float4(add.x, add.y, add.z, p_light > 0.0f ? 1.0f : 0.0f);
+        flags |= QF_SHADOW;
+    }
+
+    // throughput and next ray (:241-250)
+    V3 bsdf_val_cos = bs.spectrum * fabsf(bs.dir_in.z);
+    beta = mul_elemwise(beta, bsdf_val_cos) / bs.pdf;
+    prev_pdf = bs.pdf;
+    V3 nd = to_world_coords(bs.dir_in, normal);
+
+    if (bs.is_transmission && ob.has_medium_interface)  // :252-261
+        medium = front_face ? ob.medium_inside : ob.medium_outside;
+
+    // Russian roulette (:263-272)
+    float q = 1.0f - max_elem(beta);
+    if (rng.f32() < q) return flags;
+    beta = div_assign(beta, 1.0f - q);
+
+    pa.ray_o[slot] = make_float4(interaction_point.x, interaction_point.y, interaction_point.z, 0.0f);
+    pa.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, prev_pdf);
+    pa.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+    pa.meta[slot] = make_uint4(depth, bounce, (uint32_t)medium, bs.is_specular ? PF_PREV_SPECULAR : 0u);
+    if (depth > 0) flags |= QF_ALIVE;
+    return flags;
+}
+
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa, RenderParams rp,
+                                                       const uint32_t* queue, uint32_t n, uint32_t n_blocks) {
+    __shared__ uint32_t wave_cnt[2][SHADE_BLOCK / 64];
+    uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+    uint32_t flags = 0;
+    if (i < n) {
+        flags = shade_path(sc, pa, rp, queue[i]);
+        pa.qflags[i] = flags;
+    }
+    // block totals for the compaction scan (wave ballots)
+    unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
+    unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
+    uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        wave_cnt[0][wave] = (uint32_t)__popcll(alive);
+        wave_cnt[1][wave] = (uint32_t)__popcll(shadow);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t s = 0;
+        for (int w = 0; w < SHADE_BLOCK / 64; ++w) s += wave_cnt[threadIdx.x][w];
+        pa.block_cnt[threadIdx.x * n_blocks + blockIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------- compact
+// Exclusive scan of the per-block totals (one workgroup of 16 waves; at most 65 536 blocks per
+// batch): per-thread serial sums, wave-level shuffle scan, then a scan of the 16 wave totals.
+__global__ __launch_bounds__(1024) void k_compact_scan(PathArrays pa, uint32_t n_blocks) {
+    __shared__ uint32_t wave_sum[2][16];
+    const uint32_t per = (n_blocks + 1023u) / 1024u;
+    const uint32_t begin = threadIdx.x * per, end = min(begin + per, n_blocks);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t own[2], incl[2];
+    for (int q = 0; q < 2; ++q) {
+        uint32_t s = 0;
+        for (uint32_t b = begin; b < end; ++b) s += pa.block_cnt[q * n_blocks + b];
+        own[q] = s;
+        uint32_t x = s;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t y = __shfl_up(x, off);
+            if (lane >= (uint32_t)off) x += y;
+        }
+        incl[q] = x;
+        if (lane == 63) wave_sum[q][wave] = x;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int q = 0; q < 2; ++q) {
+            uint32_t w = lane < 16 ? wave_sum[q][lane] : 0u;
+            uint32_t x = w;
+            for (int off = 1; off < 16; off <<= 1) {
+                uint32_t y = __shfl_up(x, off);
+                if (lane >= (uint32_t)off) x += y;
+            }
+            if (lane < 16) wave_sum[q][lane] = x - w;  // exclusive
+            if (lane == 15) pa.totals[q] = x;
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < 2; ++q) {
+        uint32_t run = incl[q] - own[q] + wave_sum[q][wave];
+        for (uint32_t b = begin; b < end; ++b) {
+            pa.block_off[q * n_blocks + b] = run;
+            run += pa.block_cnt[q * n_blocks + b];
+        }
+    }
+}
+
+// Stable scatter: position = block offset + waves before + rank inside the wave ballot.
+__global__ __launch_bounds__(SHADE_BLOCK) void k_compact_scatter(PathArrays pa, const uint32_t* queue,
+                                                                 uint32_t* next_queue, uint32_t n, uint32_t n_blocks) {
+    __shared__ uint32_t wave_cnt[2][SHADE_BLOCK / 64];
+    uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+    uint32_t flags = i < n ? pa.qflags[i] : 0u;
+    uint32_t slot = i < n ? queue[i] : 0u;
+    unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
+    unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
+    uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        wave_cnt[0][wave] = (uint32_t)__popcll(alive);
+        wave_cnt[1][wave] = (uint32_t)__popcll(shadow);
+    }
+    __syncthreads();
+    unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (flags & QF_ALIVE) {
+        uint32_t pos = pa.block_off[blockIdx.x];
+        for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[0][w];
+        next_queue[pos + (uint32_t)__popcll(alive & below)] = slot;
+    }
+    if (flags & QF_SHADOW) {
+        uint32_t pos = pa.block_off[n_blocks + blockIdx.x];
+        for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[1][w];
+        pa.shadow_q[pos + (uint32_t)__popcll(shadow & below)] = slot;
+    }
+}
+
+// ---------------------------------------------------------------- resolve
+// colour += ray_colour(...) over the samples of the batch, in sample order (:302-308).
+__global__ __launch_bounds__(256) void k_resolve(PathArrays pa, float* rgb_sum, uint32_t npix, uint32_t s_count,
+                                                 int first_batch) {
+    uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    if (pixel >= npix) return;
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+    if (!first_batch) {
+        cx = rgb_sum[3 * (size_t)pixel];
+        cy = rgb_sum[3 * (size_t)pixel + 1];
+        cz = rgb_sum[3 * (size_t)pixel + 2];
+    }
+    for (uint32_t s = 0; s < s_count; ++s) {
+        float4 r = pa.rad[(size_t)s * npix + pixel];
+        cx += r.x;
+        cy += r.y;
+        cz += r.z;
+    }
+    rgb_sum[3 * (size_t)pixel] = cx;
+    rgb_sum[3 * (size_t)pixel + 1] = cy;
+    rgb_sum[3 * (size_t)pixel + 2] = cz;
+}
+
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+struct StageTimer {  // accumulates HIP-event time of one pipeline stage on the context stream
+    hipEvent_t a = nullptr, b = nullptr;
+    float ms = 0.0f;
+    bool pending = false;
+};
+
+}  // namespace
+
+extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp_first, uint32_t spp_count,
+                         uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats) {
+    if (!ctx || !rgb_sum) {
+        rth::set_error("rt_render: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (!ctx->has_scene) {
+        rth::set_error("rt_render: no scene uploaded (call rt_upload_scene first)");
+        return RT_ERR_STATE;
+    }
+    if (width < 2 || height < 2) {  // the reference divides by (w-1), (h-1) (:303-304)
+        rth::set_error("rt_render: width and height must be >= 2");
+        return RT_ERR_INVALID;
+    }
+    const uint64_t npix64 = (uint64_t)width * height;
+    if (npix64 > 0x7FFFFFFFull) {
+        rth::set_error("rt_render: image too large");
+        return RT_ERR_LIMIT;
+    }
+    const uint32_t npix = (uint32_t)npix64;
+    if (ctx->scene.n_lights == 0 && ctx->scene.n_objects > 0) {
+        // sample_lights_uniform would index an empty Vec (panic) on the first non-specular hit
+        rth::set_error("rt_render: scene has no lights (the reference panics in sample_lights_uniform)");
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = ctx->stream;
+
+    // ---- batch size: samples in flight at once
+    uint64_t max_paths = ctx->max_paths_in_flight ? ctx->max_paths_in_flight : (uint64_t)8 << 20;
+    uint32_t s_batch = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
+    if (s_batch > spp_count) s_batch = spp_count ? spp_count : 1;
+    while ((uint64_t)s_batch * npix > 0x7FFFFFFFull) --s_batch;
+    const uint64_t P = (uint64_t)s_batch * npix;
+    const uint32_t max_blocks = (uint32_t)((P + SHADE_BLOCK - 1) / SHADE_BLOCK);
+
+    // ---- carve the path state out of one allocation
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    size_t o_ray_o = carve(P * 16), o_ray_d = carve(P * 16), o_beta = carve(P * 16), o_rad = carve(P * 16),
+           o_meta = carve(P * 16), o_hit_a = carve(P * 16), o_hit_b = carve(P * 8), o_sh_o = carve(P * 16),
+           o_sh_d = carve(P * 16), o_sh_c = carve(P * 16), o_q0 = carve(P * 4), o_q1 = carve(P * 4),
+           o_sq = carve(P * 4), o_qf = carve(P * 4), o_bc = carve((size_t)max_blocks * 8),
+           o_bo = carve((size_t)max_blocks * 8), o_tot = carve(256), o_vis = carve(256);
+    int rc = ctx->path_state.ensure(off);
+    if (rc != RT_OK) return rc;
+    char* base = (char*)ctx->path_state.p;
+    PathArrays pa;
+    pa.ray_o = (float4*)(base + o_ray_o);
+    pa.ray_d = (float4*)(base + o_ray_d);
+    pa.beta = (float4*)(base + o_beta);
+    pa.rad = (float4*)(base + o_rad);
+    pa.meta = (uint4*)(base + o_meta);
+    pa.hit_a = (float4*)(base + o_hit_a);
+    pa.hit_b = (uint2*)(base + o_hit_b);
+    pa.sh_o = (float4*)(base + o_sh_o);
+    pa.sh_d = (float4*)(base + o_sh_d);
+    pa.sh_c = (float4*)(base + o_sh_c);
+    pa.queue[0] = (uint32_t*)(base + o_q0);
+    pa.queue[1] = (uint32_t*)(base + o_q1);
+    pa.shadow_q = (uint32_t*)(base + o_sq);
+    pa.qflags = (uint32_t*)(base + o_qf);
+    pa.block_cnt = (uint32_t*)(base + o_bc);
+    pa.block_off = (uint32_t*)(base + o_bo);
+    pa.totals = (uint32_t*)(base + o_tot);
+    pa.visit = (unsigned long long*)(base + o_vis);
+    RT_HIP(hipMemsetAsync(pa.visit, 0, 256, stream));
+
+    // ---- output: device accumulator (the caller's buffer if it is device memory)
+    float* d_sum = rgb_sum;
+    const size_t sum_bytes = (size_t)npix * 3 * sizeof(float);
+    const bool host_out = !is_device_ptr(rgb_sum);
+    if (host_out) {
+        if ((rc = ctx->sample_sum.ensure(sum_bytes)) != RT_OK) return rc;
+        d_sum = (float*)ctx->sample_sum.p;
+    }
+
+    const int trace_grid_max = RT_TRACE_GRID;
+    if ((rc = rt_ctx_ensure_overflow(ctx, (size_t)trace_grid_max * RT_BLOCK)) != RT_OK) return rc;
+    const uint32_t ostride = (uint32_t)trace_grid_max * RT_BLOCK;
+    uint32_t* overflow = (uint32_t*)ctx->overflow.p;
+
+    const bool count = (flags & RT_RENDER_COUNT_VISITS) != 0;
+    const bool timing = (flags & RT_RENDER_TIME_STAGES) != 0;
+    StageTimer tm[5];  // generate, extend, shade, shadow, compact
+    if (timing)
+        for (StageTimer& t : tm) {
+            RT_HIP(hipEventCreate(&t.a));
+            RT_HIP(hipEventCreate(&t.b));
+        }
+    auto t_begin = [&](int k) -> int {
+        if (timing) RT_HIP(hipEventRecord(tm[k].a, stream));
+        return RT_OK;
+    };
+    auto t_end = [&](int k) -> int {
+        if (timing) {
+            RT_HIP(hipEventRecord(tm[k].b, stream));
+            tm[k].pending = true;
+        }
+        return RT_OK;
+    };
+    auto t_collect = [&]() -> int {  // after a stream sync
+        for (StageTimer& t : tm)
+            if (t.pending) {
+                float ms = 0.0f;
+                RT_HIP(hipEventElapsedTime(&ms, t.a, t.b));
+                t.ms += ms;
+                t.pending = false;
+            }
+        return RT_OK;
+    };
+
+    rt_stats st;
+    memset(&st, 0, sizeof st);
+    RT_HIP(hipEventRecord(ctx->ev[0], stream));
+
+    RenderParams rp;
+    rp.width = width;
+    rp.height = height;
+    rp.npix = npix;
+    rp.depth = depth;
+    rp.k0 = (uint32_t)seed;
+    rp.k1 = (uint32_t)(seed >> 32);
+
+    if (spp_count == 0) RT_HIP(hipMemsetAsync(d_sum, 0, sum_bytes, stream));
+    bool first_batch = true;
+    for (uint32_t s0 = 0; s0 < spp_count; s0 += s_batch) {
+        const uint32_t s_count = std::min(s_batch, spp_count - s0);
+        const uint32_t n_paths = s_count * npix;
+        rp.sample_first = spp_first + s0;
+        if ((rc = t_begin(0)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, pa, rp, n_paths);
+        if ((rc = t_end(0)) != RT_OK) return rc;
+        st.paths += n_paths;
+        st.batches += 1;
+
+        uint32_t n = depth > 0 ? n_paths : 0;
+        int cur = 0;
+        uint32_t iter = 0;
+        while (n > 0) {
+            if (iter >= 1u << 20) {
+                rth::set_error("rt_render: wavefront did not drain after 2^20 iterations");
+                return RT_ERR_LIMIT;
+            }
+            const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
+            const int tgrid = (int)std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
+            if ((rc = t_begin(1)) != RT_OK) return rc;
+            if (count)
+                hipLaunchKernelGGL(k_extend<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                                   pa.queue[cur], n, overflow, ostride);
+            else
+                hipLaunchKernelGGL(k_extend<false>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                                   pa.queue[cur], n, overflow, ostride);
+            if ((rc = t_end(1)) != RT_OK) return rc;
+            st.rays_closest += n;
+            st.launches_extend += 1;
+
+            if ((rc = t_begin(2)) != RT_OK) return rc;
+            hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pa, rp,
+                               pa.queue[cur], n, n_blocks);
+            if ((rc = t_end(2)) != RT_OK) return rc;
+
+            if ((rc = t_begin(4)) != RT_OK) return rc;
+            hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, stream, pa, n_blocks);
+            hipLaunchKernelGGL(k_compact_scatter, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, pa, pa.queue[cur],
+                               pa.queue[cur ^ 1], n, n_blocks);
+            if ((rc = t_end(4)) != RT_OK) return rc;
+
+            uint32_t totals[2];
+            RT_HIP(hipMemcpyAsync(totals, pa.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
+            RT_HIP(hipStreamSynchronize(stream));
+            if ((rc = t_collect()) != RT_OK) return rc;
+            const uint32_t n_next = totals[0], n_shadow = totals[1];
+            if (n_next > n || n_shadow > n) {
+                rth::set_error("rt_render: compaction produced impossible counts");
+                return RT_ERR_HIP;
+            }
+            if (n_shadow > 0) {
+                const int sgrid = (int)std::min<uint32_t>((n_shadow + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
+                if ((rc = t_begin(3)) != RT_OK) return rc;
+                if (count)
+                    hipLaunchKernelGGL(k_shadow<true>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
+                                       overflow, ostride);
+                else
+                    hipLaunchKernelGGL(k_shadow<false>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                                       n_shadow, overflow, ostride);
+                if ((rc = t_end(3)) != RT_OK) return rc;
+                st.rays_shadow += n_shadow;
+                st.launches_shadow += 1;
+            }
+            n = n_next;
+            cur ^= 1;
+            ++iter;
+        }
+        if (iter > st.iterations) st.iterations = iter;
+        hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, stream, pa, d_sum, npix, s_count,
+                           first_batch ? 1 : 0);
+        first_batch = false;
+    }
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(ctx->ev[1], stream));
+    unsigned long long visit[4] = {0, 0, 0, 0};
+    if (count) RT_HIP(hipMemcpyAsync(visit, pa.visit, sizeof visit, hipMemcpyDeviceToHost, stream));
+    if (host_out) RT_HIP(hipMemcpyAsync(rgb_sum, d_sum, sum_bytes, hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    if ((rc = t_collect()) != RT_OK) return rc;
+    RT_HIP(hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[1]));
+    st.nodes_visited = visit[0];
+    st.tris_tested = visit[1];
+    st.nodes_visited_shadow = visit[2];
+    st.tris_tested_shadow = visit[3];
+    st.ms_generate = tm[0].ms;
+    st.ms_extend = tm[1].ms;
+    st.ms_shade = tm[2].ms;
+    st.ms_shadow = tm[3].ms;
+    st.ms_compact = tm[4].ms;
+    if (timing)
+        for (StageTimer& t : tm) {
+            (void)hipEventDestroy(t.a);
+            (void)hipEventDestroy(t.b);
+        }
+    if (stats) *stats = st;
+    return RT_OK;
 }
