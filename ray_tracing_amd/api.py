@@ -365,7 +365,7 @@ class Scene:
         return np.ctypeslib.as_array(self.flat.tri_prim_id, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
 
     def bvhs(self):
-        return [self.flat.bvhs[i] for i in range(self.flat.n_bvhs)]
+        return [BvhFlat.from_buffer_copy(self.flat.bvhs[i]) for i in range(self.flat.n_bvhs)]
 
     def __del__(self):
         if getattr(self, "handle", None):
