@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--max-paths", type=int, default=0, help="paths in flight per batch (0 = library default)")
     return ap.parse_args()
 
 
@@ -80,6 +81,8 @@ def main():
     scene = rt.Scene(desc)
     ctx = rt.Context(local_rank)
     ctx.upload(scene)
+    if args.max_paths:
+        ctx.set_max_paths_in_flight(args.max_paths)
     setup_s = time.time() - t_setup
     n_tris = scene.flat.n_tris
 

@@ -5,7 +5,7 @@
 #include <string>
 #include <vector>
 
-#include "device_scene.h"
+#include "device_trace.h"
 
 namespace rth {
 void set_error(const char* fmt, ...);
@@ -48,3 +48,6 @@ struct rt_ctx {
 };
 
 int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes);
+
+// Scheduler parameters of the persistent trace kernels for a launch of n rays on `grid` blocks.
+rtd::TraceTune rt_trace_tune(size_t n, int grid);

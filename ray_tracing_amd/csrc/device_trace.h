@@ -1,0 +1,259 @@
+// Persistent-wave ray traversal: the hot loop behind rt_trace_closest / rt_trace_any / k_extend /
+// k_shadow.
+//
+// Why this shape (PMC profile of the first version, profiles/r01/pmc_trace_v0): with one static
+// strip of rays per lane the grid averaged 1.2 resident waves per SIMD (rays over background
+// finish at once, waves over the mesh run long) and a wave stalled on its slowest ray.  Here
+//   * a launch is a fixed number of waves that PULL rays from a global counter, so the chip stays
+//     full until the queue is empty;
+//   * each lane is a small state machine (advance-object / internal node / leaf) and an idle lane
+//     is refilled with a new ray as soon as >= refill_min lanes of its wave are idle, so one long
+//     ray no longer parks 63 lanes;
+//   * per ray the arithmetic and the visiting order are still exactly those of
+//     Engine::hit -> Object::hit -> traverse_bvh (path_integrator.rs:88-104, object.rs:32-87,
+//     bvh.rs:243-300): the schedule changes, the result (and the visit counters) do not.
+#pragma once
+#include "device_scene.h"
+
+namespace rtd {
+
+// Launch-time tuning of the wave scheduler (uniform kernel argument).
+struct TraceTune {
+    uint32_t chunk;       // rays a wave takes from the global work counter per atomic
+    uint32_t refill_min;  // idle lanes that trigger a refill
+    uint32_t w_adv, w_node, w_leaf;  // phase weights: each loop iteration runs the ONE phase with the largest
+                                     // (lanes waiting for it) x weight
+};
+
+constexpr uint32_t RAY_NONE = 0xFFFFFFFFu;
+constexpr uint32_t REF_ADVANCE = 0xFFFFFFFFu;  // "current object finished": never a valid leaf ref
+
+// 64-byte child pair / 48-byte triangle fetches with a 32-bit byte offset from a uniform base
+// (global_load_dwordx4 v, v_off, s[base]); rt_upload_scene bounds both arrays to < 4 GiB.
+RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float4*>(static_cast<const char*>(base) + byte_off);
+}
+
+template <bool ANY, bool COUNT, int STACK_LDS, int BLOCK, class IO>
+RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
+                       float t_max_in,
+                       uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64u - lane));
+    Stack<STACK_LDS, BLOCK> st;
+    st.lds = lds;
+    st.overflow = overflow;
+    st.overflow_stride = overflow_stride;
+    st.sp = 0;
+
+    const uint32_t refill_min = tune.refill_min, chunk = tune.chunk;
+    uint32_t ray = RAY_NONE;
+    bool more = true;
+    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
+    V3 wo = v3(0, 0, 0), wd = v3(0, 0, 0);            // world-space ray
+    V3 o = wo, d = wd, inv = wd;                      // object-space ray of the current object
+    float nr = 1.0f;                                  // |M^-1 d|^-1 of the current object
+    uint32_t obj = 0;
+    uint32_t cur = REF_ADVANCE;
+    float tmax = 0.0f;                                // running t_max inside the current object
+    float best_t = 0.0f;                              // Engine::hit's shrinking t_max (world)
+    V3 best_n = wo;
+    uint32_t best_meta = RT_MISS, best_prim = RT_MISS;
+    uint32_t hit_tri = 0, hit_ff = 0;
+    bool obj_hit = false, fresh = false;
+    Visits vis = {0, 0};
+
+    for (;;) {
+        // ---------------------------------------------------------------- refill idle lanes
+        // The wave owns a pool [pool_next, pool_end) of consecutive ray indices taken from the
+        // global counter `chunk` at a time (one atomic per chunk; the host sizes it so that every
+        // wave of the launch comes back for work several times -- a tail of full pools is a static split again); idle lanes draw from it.
+        if (more) {
+            const bool idle = ray == RAY_NONE;
+            const unsigned long long m = __ballot(idle);
+            const uint32_t n_idle = (uint32_t)__popcll(m);
+            if (n_idle >= refill_min || (n_idle > 0 && __ballot(!idle) == 0ull)) {
+                if (pool_next == pool_end) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(work_counter, chunk);
+                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    if (b >= n) {
+                        more = false;
+                    } else {
+                        pool_next = b;
+                        pool_end = min(b + chunk, n);
+                    }
+                }
+                if (more) {
+                    const uint32_t take = min(n_idle, pool_end - pool_next);
+                    const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
+                    if (idle && rank < take) {
+                        ray = pool_next + rank;
+                        io.load(ray, &wo, &wd);
+                        best_t = t_max_in;
+                        best_meta = RT_MISS;
+                        cur = REF_ADVANCE;
+                        obj_hit = false;
+                        fresh = true;
+                        st.sp = 0;
+                        if (COUNT) vis = {0, 0};
+                    }
+                    pool_next += take;
+                }
+            }
+        }
+        // ---------------------------------------------------------------- pick ONE phase
+        // PMC of the run-every-phase version: 24 % VALU lane utilisation (a phase ran whenever a
+        // single lane needed it).  Lanes now wait in their state until their phase is the best use
+        // of the next issue slots; only that phase runs in this iteration.
+        const bool adv = ray != RAY_NONE && cur == REF_ADVANCE;
+        const bool isnode = ray != RAY_NONE && (cur & LEAF_BIT) == 0u;
+        const bool isleaf = ray != RAY_NONE && (cur & LEAF_BIT) != 0u && cur != REF_ADVANCE;
+        const uint32_t s_adv = (uint32_t)__popcll(__ballot(adv)) * tune.w_adv;
+        const uint32_t s_node = (uint32_t)__popcll(__ballot(isnode)) * tune.w_node;
+        const uint32_t s_leaf = (uint32_t)__popcll(__ballot(isleaf)) * tune.w_leaf;
+        if ((s_adv | s_node | s_leaf) == 0u) break;
+        const bool run_node = s_node >= s_leaf && s_node >= s_adv;
+        const bool run_leaf = !run_node && s_leaf >= s_adv;
+        const bool run_adv = !run_node && !run_leaf;
+
+        // ---------------------------------------------------------------- A: next object
+        if (run_adv) {
+            if (adv) {
+                if (obj_hit) {  // close the mesh traversal that just ended (Object::hit tail, object.rs:56-65)
+                    const DObject& ob = sc.objects[obj];
+                    float4 q0 = ld16(sc.tris, hit_tri * 48u), q1 = ld16(sc.tris, hit_tri * 48u + 16u),
+                           q2 = ld16(sc.tris, hit_tri * 48u + 32u);
+                    V3 nrm = normalise(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));  // primitives.rs:175
+                    float t = tmax;
+                    if (ob.has_transform) {
+                        t = t * nr;
+                        nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
+                    }
+                    best_t = t;
+                    best_n = nrm;
+                    best_meta = obj | (hit_ff << 31);
+                    best_prim = __float_as_uint(q0.w);
+                    obj_hit = false;
+                }
+                for (;;) {  // Engine::hit's loop over objects (path_integrator.rs:90-95)
+                    obj = fresh ? 0u : obj + 1u;
+                    fresh = false;
+                    if (obj >= sc.n_objects) {
+                        if (ANY) io.emit_any(ray, false, vis);
+                        else io.emit_closest(ray, best_meta != RT_MISS, best_t, best_n, best_meta, best_prim, vis);
+                        ray = RAY_NONE;
+                        break;
+                    }
+                    const DObject& ob = sc.objects[obj];
+                    o = wo;
+                    d = wd;
+                    if (ob.has_transform) {  // object.rs:39-45
+                        o = mat_mul(ob.inv_m, wo) + v3(ob.inv_t[0], ob.inv_t[1], ob.inv_t[2]);
+                        d = mat_mul(ob.inv_m, wd);
+                        nr = norm_recip(d);
+                        d = d * nr;
+                    }
+                    const float t_lim = ANY ? t_max_in : best_t;
+                    if (ob.kind == RT_SURF_MESH) {
+                        inv = v3(recip(d.x), recip(d.y), recip(d.z));
+                        tmax = t_lim;
+                        cur = ob.root_ref;
+                        st.sp = 0;
+                        break;
+                    }
+                    float t = 0.0f;
+                    V3 nrm = wo;
+                    uint32_t ff = 0;
+                    bool h = false;
+                    if (ob.kind == RT_SURF_SPHERE) {
+                        h = sphere_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), ob.surf[3], o, d, t_min, t_lim, &t, &nrm, &ff);
+                    } else if (ob.kind == RT_SURF_PLANE) {
+                        nrm = v3(ob.surf[0], ob.surf[1], ob.surf[2]);
+                        h = plane_hit(nrm, ob.surf[3], o, d, t_min, t_lim, &t, &ff);
+                    } else if (ob.kind == RT_SURF_TRIANGLE) {
+                        V3 e1 = v3(ob.surf[3], ob.surf[4], ob.surf[5]), e2 = v3(ob.surf[6], ob.surf[7], ob.surf[8]);
+                        float det;
+                        h = tri_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), e1, e2, o, d, t_min, t_lim, &t, &det);
+                        nrm = normalise(cross(e1, e2));
+                        ff = det > 0.0f;
+                    }
+                    if (h) {
+                        if (ANY) {
+                            io.emit_any(ray, true, vis);
+                            ray = RAY_NONE;
+                            break;
+                        }
+                        if (ob.has_transform) {
+                            t = t * nr;
+                            nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
+                        }
+                        best_t = t;
+                        best_n = nrm;
+                        best_meta = obj | (ff << 31);
+                        best_prim = 0;
+                    }
+                }
+            }
+        }
+
+        // ---------------------------------------------------------------- B: internal node
+        if (run_node) {
+            if (isnode) {
+                const uint32_t off = cur << 6;
+                float4 a0 = ld16(sc.pairs, off), a1 = ld16(sc.pairs, off + 16u), b0 = ld16(sc.pairs, off + 32u),
+                       b1 = ld16(sc.pairs, off + 48u);
+                if (COUNT) vis.n_int += 1;
+                float lo1[3] = {a0.x, a0.y, a0.z}, hi1[3] = {a0.w, a1.x, a1.y};
+                float lo2[3] = {b0.x, b0.y, b0.z}, hi2[3] = {b0.w, b1.x, b1.y};
+                const uint32_t ref1 = __float_as_uint(a1.z), ref2 = __float_as_uint(b1.z);
+                float t1, t2;
+                const bool h1 = aabb_hit(lo1, hi1, o, inv, t_min, tmax, &t1);
+                const bool h2 = aabb_hit(lo2, hi2, o, inv, t_min, tmax, &t2);
+                if (h1 && h2) {  // bvh.rs:287-295: far pushed, near next; near = child1 unless t1 > t2
+                    const bool swap = t1 > t2;
+                    st.push(swap ? ref1 : ref2);
+                    cur = swap ? ref2 : ref1;
+                } else if (h1) {
+                    cur = ref1;
+                } else if (h2) {
+                    cur = ref2;
+                } else {
+                    cur = st.sp == 0 ? REF_ADVANCE : st.pop();
+                }
+            }
+        }
+
+        // ---------------------------------------------------------------- C: leaf
+        if (run_leaf) {
+            if (isleaf) {
+                uint32_t k = cur & ~LEAF_BIT;
+                uint32_t last;
+                bool done = false;
+                do {  // primitives in `indices` order (bvh.rs:256-266)
+                    float4 q0 = ld16(sc.tris, k * 48u), q1 = ld16(sc.tris, k * 48u + 16u), q2 = ld16(sc.tris, k * 48u + 32u);
+                    if (COUNT) vis.n_tri += 1;
+                    float t, det;
+                    if (tri_hit(v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), o, d, t_min, tmax, &t,
+                                &det)) {
+                        if (ANY) {
+                            io.emit_any(ray, true, vis);
+                            ray = RAY_NONE;
+                            done = true;
+                            break;
+                        }
+                        tmax = t;
+                        hit_tri = k;
+                        hit_ff = det > 0.0f;
+                        obj_hit = true;
+                    }
+                    last = __float_as_uint(q1.w);
+                    ++k;
+                } while (!last);
+                if (!done) cur = st.sp == 0 ? REF_ADVANCE : st.pop();
+            }
+        }
+    }
+}
+
+}  // namespace rtd

@@ -1,6 +1,8 @@
 // Device context, scene upload and the batch intersector entry points (rt_trace_closest /
 // rt_trace_any).  gfx950 only; compiled with -ffp-contract=off (see device_math.h).
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "context.h"
@@ -32,62 +34,61 @@ int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes) {
     return ctx->overflow.ensure(lanes * ctx->overflow_levels * sizeof(uint32_t));
 }
 
-// ---------------------------------------------------------------- kernels
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DScene sc, rt_rays rays, size_t n, float t_min,
-                                                            float t_max, rt_hits out, uint32_t* overflow,
-                                                            uint32_t overflow_stride) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    const size_t gtid = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
-    const size_t total = (size_t)gridDim.x * RT_BLOCK;
-    Stack<RT_STACK_LDS, RT_BLOCK> st;
-    st.lds = lds_stack + threadIdx.x;
-    st.overflow = overflow + gtid;
-    st.overflow_stride = overflow_stride;
-    st.sp = 0;
-    for (size_t i = gtid; i < n; i += total) {
-        V3 o = v3(rays.ox[i], rays.oy[i], rays.oz[i]);
-        V3 d = v3(rays.dx[i], rays.dy[i], rays.dz[i]);
-        Hit h;
-        Visits vis = {0, 0};
-        bool got = scene_hit<COUNT, RT_STACK_LDS, RT_BLOCK>(sc, o, d, t_min, t_max, st, &h, &vis);
-        out.t[i] = got ? h.t : __builtin_inff();
-        if (out.prim) out.prim[i] = got ? h.prim : RT_MISS;
-        if (out.obj) out.obj[i] = got ? h.obj : RT_MISS;
-        if (out.nx) out.nx[i] = got ? h.normal.x : 0.0f;
-        if (out.ny) out.ny[i] = got ? h.normal.y : 0.0f;
-        if (out.nz) out.nz[i] = got ? h.normal.z : 0.0f;
-        if (out.front_face) out.front_face[i] = got ? (uint8_t)h.front_face : (uint8_t)0;
-        if (COUNT) {
-            if (out.n_int) out.n_int[i] = vis.n_int;
-            if (out.n_tri) out.n_tri[i] = vis.n_tri;
+TraceTune rt_trace_tune(size_t n, int grid) {
+    // Defaults from sweeps on MI355X (profiles/r01/tuning.md); RT_TUNE="chunk,refill,w_adv,w_node,w_leaf"
+    // overrides them for experiments.
+    static TraceTune t = {0, 0, 0, 0, 0};
+    if (t.chunk == 0) {
+        TraceTune d = {64, 16, 1, 2, 3};
+        const char* e = getenv("RT_TUNE");
+        if (e) {
+            unsigned v[5] = {d.chunk, d.refill_min, d.w_adv, d.w_node, d.w_leaf};
+            sscanf(e, "%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4]);
+            d = {v[0] ? v[0] : 64u, v[1] ? (v[1] > 64u ? 64u : v[1]) : 1u, v[2], v[3], v[4]};
+            if (d.w_adv + d.w_node + d.w_leaf == 0 || !d.w_adv || !d.w_node || !d.w_leaf) d = {d.chunk, d.refill_min, 1, 2, 3};
         }
+        t = d;
     }
+    (void)n;
+    (void)grid;
+    return t;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DScene sc, rt_rays rays, size_t n, float t_min, float t_max,
-                                                        uint8_t* occluded, uint32_t* n_int, uint32_t* n_tri,
-                                                        uint32_t* overflow, uint32_t overflow_stride) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    const size_t gtid = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
-    const size_t total = (size_t)gridDim.x * RT_BLOCK;
-    Stack<RT_STACK_LDS, RT_BLOCK> st;
-    st.lds = lds_stack + threadIdx.x;
-    st.overflow = overflow + gtid;
-    st.overflow_stride = overflow_stride;
-    st.sp = 0;
-    for (size_t i = gtid; i < n; i += total) {
-        V3 o = v3(rays.ox[i], rays.oy[i], rays.oz[i]);
-        V3 d = v3(rays.dx[i], rays.dy[i], rays.dz[i]);
-        Visits vis = {0, 0};
-        bool got = scene_hit_bool<COUNT, RT_STACK_LDS, RT_BLOCK>(sc, o, d, t_min, t_max, st, &vis);
-        occluded[i] = got ? 1 : 0;
-        if (COUNT) {
-            if (n_int) n_int[i] = vis.n_int;
-            if (n_tri) n_tri[i] = vis.n_tri;
-        }
+// ---------------------------------------------------------------- kernels
+struct TraceIO {  // caller-provided SoA ray batch and hit arrays (rt_rays / rt_hits)
+    rt_rays rays;
+    rt_hits out;
+    uint8_t* occluded;
+    RT_DEV void load(uint32_t i, V3* o, V3* d) const {
+        *o = v3(rays.ox[i], rays.oy[i], rays.oz[i]);
+        *d = v3(rays.dx[i], rays.dy[i], rays.dz[i]);
     }
+    RT_DEV void emit_closest(uint32_t i, bool got, float t, V3 n, uint32_t meta, uint32_t prim, const Visits& vis) const {
+        out.t[i] = got ? t : __builtin_inff();
+        if (out.prim) out.prim[i] = got ? prim : RT_MISS;
+        if (out.obj) out.obj[i] = got ? (meta & 0x7FFFFFFFu) : RT_MISS;
+        if (out.nx) out.nx[i] = got ? n.x : 0.0f;
+        if (out.ny) out.ny[i] = got ? n.y : 0.0f;
+        if (out.nz) out.nz[i] = got ? n.z : 0.0f;
+        if (out.front_face) out.front_face[i] = got ? (uint8_t)(meta >> 31) : (uint8_t)0;
+        if (out.n_int) out.n_int[i] = vis.n_int;
+        if (out.n_tri) out.n_tri[i] = vis.n_tri;
+    }
+    RT_DEV void emit_any(uint32_t i, bool occ, const Visits& vis) const {
+        occluded[i] = occ ? 1 : 0;
+        if (out.n_int) out.n_int[i] = vis.n_int;
+        if (out.n_tri) out.n_tri[i] = vis.n_tri;
+    }
+};
+
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceIO io, uint32_t n, float t_min, float t_max,
+                                                    uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
+                                                    uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    trace_loop<ANY, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, t_min, t_max, lds_stack + threadIdx.x,
+                                                   overflow + gtid, overflow_stride);
 }
 
 // ---------------------------------------------------------------- helpers
@@ -230,6 +231,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
     // ---- BVHs: validate every mesh tree on the host (a malformed tree must never reach a kernel),
     //      measure its depth, and re-lay it out as aligned child pairs.
     std::vector<DPair> pairs;
+    if ((uint64_t)s->n_tris * 48ull >= (1ull << 32)) {
+        rth::set_error("rt_upload_scene: more than 4 GiB of triangles (89 478 485)");
+        return RT_ERR_LIMIT;
+    }
     std::vector<float4> tris((size_t)s->n_tris * 3);
     std::vector<uint32_t> root_ref(s->n_bvhs);
     uint32_t stack_need = 0;
@@ -258,8 +263,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
         uint32_t pair_base = (uint32_t)pairs.size(), n_internal = 0;
         for (uint32_t k = 0; k < b.node_count; ++k)
             if (nnp[k] == 0) pair_id[k] = pair_base + n_internal++;
-        if ((uint64_t)pair_base + n_internal >= LEAF_BIT) {
-            rth::set_error("rt_upload_scene: more than 2^31 internal nodes");
+        if (((uint64_t)pair_base + n_internal) * sizeof(DPair) >= (1ull << 32)) {
+            rth::set_error("rt_upload_scene: more than 4 GiB of BVH nodes (2^26 internal nodes)");
             return RT_ERR_LIMIT;
         }
         pairs.resize((size_t)pair_base + n_internal);
@@ -461,17 +466,28 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
         (rc = sg.out(hits->front_face, n, (void**)&dh.front_face)) ||
         (rc = sg.out(hits->n_int, fb, (void**)&dh.n_int)) || (rc = sg.out(hits->n_tri, fb, (void**)&dh.n_tri)))
         return rc;
+    if (n > 0xFFFFFFF0ull) {
+        rth::set_error("rt_trace_closest: batch larger than 2^32 rays");
+        return RT_ERR_LIMIT;
+    }
     int grid = trace_grid(n);
     size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
+    if ((rc = ctx->counters.ensure(256)) != RT_OK) return rc;
+    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, 4, ctx->stream));
     bool count = dh.n_int || dh.n_tri;
+    TraceIO io{dr, dh, nullptr};
     RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (count)
-        hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n,
-                           t_min, t_max, dh, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
+        hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
+                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
+                           (uint32_t*)ctx->overflow.p,
+                           (uint32_t)lanes);
     else
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n,
-                           t_min, t_max, dh, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
+        hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
+                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
+                           (uint32_t*)ctx->overflow.p,
+                           (uint32_t)lanes);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     if ((rc = sg.finish()) != RT_OK) return rc;
@@ -500,16 +516,31 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
     if ((rc = sg.out(occluded, n, (void**)&d_occ)) || (rc = sg.out(n_int, fb, (void**)&d_ni)) ||
         (rc = sg.out(n_tri, fb, (void**)&d_nt)))
         return rc;
+    if (n > 0xFFFFFFF0ull) {
+        rth::set_error("rt_trace_any: batch larger than 2^32 rays");
+        return RT_ERR_LIMIT;
+    }
     int grid = trace_grid(n);
     size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
+    if ((rc = ctx->counters.ensure(256)) != RT_OK) return rc;
+    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, 4, ctx->stream));
+    rt_hits dh;
+    memset(&dh, 0, sizeof dh);
+    dh.n_int = d_ni;
+    dh.n_tri = d_nt;
+    TraceIO io{dr, dh, d_occ};
     RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (d_ni || d_nt)
-        hipLaunchKernelGGL(k_trace_any<true>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n, t_min,
-                           t_max, d_occ, d_ni, d_nt, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
+        hipLaunchKernelGGL((k_trace<true, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
+                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
+                           (uint32_t*)ctx->overflow.p,
+                           (uint32_t)lanes);
     else
-        hipLaunchKernelGGL(k_trace_any<false>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, dr, n, t_min,
-                           t_max, d_occ, d_ni, d_nt, (uint32_t*)ctx->overflow.p, (uint32_t)lanes);
+        hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
+                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
+                           (uint32_t*)ctx->overflow.p,
+                           (uint32_t)lanes);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     if ((rc = sg.finish()) != RT_OK) return rc;

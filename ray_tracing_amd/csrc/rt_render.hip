@@ -20,6 +20,7 @@
 
 #include "context.h"
 #include "device_shade.h"
+#include "device_trace.h"
 
 using namespace rtd;
 
@@ -48,6 +49,7 @@ struct PathArrays {      // SoA over slots
     uint32_t* block_cnt; // [2][blocks]: alive, shadow totals per shade block
     uint32_t* block_off; // [2][blocks]: exclusive scan
     uint32_t* totals;    // [0] next live count, [1] shadow count
+    uint32_t* work;      // [0] extend work counter, [1] shadow work counter (zeroed per launch)
     unsigned long long* visit; // [0] n_int extend, [1] n_tri extend, [2] n_int shadow, [3] n_tri shadow
 };
 
@@ -80,66 +82,69 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
 }
 
 // ---------------------------------------------------------------- extend
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n,
-                                                     uint32_t* overflow, uint32_t overflow_stride) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t total = gridDim.x * RT_BLOCK;
-    Stack<RT_STACK_LDS, RT_BLOCK> st;
-    st.lds = lds_stack + threadIdx.x;
-    st.overflow = overflow + gtid;
-    st.overflow_stride = overflow_stride;
-    st.sp = 0;
-    Visits vis = {0, 0};
-    for (uint32_t i = gtid; i < n; i += total) {
-        uint32_t slot = queue[i];
-        float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
-        Hit h;
-        bool got = scene_hit<COUNT, RT_STACK_LDS, RT_BLOCK>(sc, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), T_MIN,
-                                                            __builtin_inff(), st, &h, &vis);
-        if (got) {
-            pa.hit_a[slot] = make_float4(h.t, h.normal.x, h.normal.y, h.normal.z);
-            pa.hit_b[slot] = make_uint2(h.obj | (h.front_face << 31), h.prim);
-        } else {
-            pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
-        }
+RT_DEV void add_visits(unsigned long long* dst, unsigned long long a, unsigned long long b) {
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
     }
-    if (COUNT) {
-        unsigned long long a = vis.n_int, b = vis.n_tri;
-        for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_down(a, off);
-            b += __shfl_down(b, off);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&pa.visit[0], a);
-            atomicAdd(&pa.visit[1], b);
-        }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&dst[0], a);
+        atomicAdd(&dst[1], b);
     }
 }
 
-// ---------------------------------------------------------------- shadow-connect
+struct ExtendIO {  // rays come from the live-path queue, hits go to the path's slot
+    PathArrays pa;
+    const uint32_t* queue;
+    unsigned long long n_int, n_tri;
+    RT_DEV void load(uint32_t i, V3* o, V3* d) const {
+        const uint32_t slot = queue[i];
+        float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
+        *o = v3(o4.x, o4.y, o4.z);
+        *d = v3(d4.x, d4.y, d4.z);
+    }
+    RT_DEV void emit_closest(uint32_t i, bool got, float t, V3 n, uint32_t meta, uint32_t prim, const Visits& vis) {
+        const uint32_t slot = queue[i];
+        if (got) {
+            pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
+            pa.hit_b[slot] = make_uint2(meta, prim);
+        } else {
+            pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
+        }
+        n_int += vis.n_int;
+        n_tri += vis.n_tri;
+    }
+    RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
+};
+
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene sc, PathArrays pa, uint32_t n, uint32_t* overflow,
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n,
+                                                     uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                      uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t total = gridDim.x * RT_BLOCK;
-    Stack<RT_STACK_LDS, RT_BLOCK> st;
-    st.lds = lds_stack + threadIdx.x;
-    st.overflow = overflow + gtid;
-    st.overflow_stride = overflow_stride;
-    st.sp = 0;
-    Visits vis = {0, 0};
-    for (uint32_t i = gtid; i < n; i += total) {
-        uint32_t slot = pa.shadow_q[i];
+    ExtendIO io{pa, queue, 0ull, 0ull};
+    trace_loop<false, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+                                                     lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
+}
+
+// ---------------------------------------------------------------- shadow-connect
+struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds its pending NEE term
+    PathArrays pa;
+    unsigned long long n_int, n_tri;
+    RT_DEV void load(uint32_t i, V3* o, V3* d) const {
+        const uint32_t slot = pa.shadow_q[i];
         float4 o4 = pa.sh_o[slot], d4 = pa.sh_d[slot];
-        // path_integrator.rs:219: T_MIN..T_MAX, not the light distance
-        bool occluded = scene_hit_bool<COUNT, RT_STACK_LDS, RT_BLOCK>(sc, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z),
-                                                                      T_MIN, __builtin_inff(), st, &vis);
+        *o = v3(o4.x, o4.y, o4.z);
+        *d = v3(d4.x, d4.y, d4.z);
+    }
+    RT_DEV void emit_closest(uint32_t, bool, float, V3, uint32_t, uint32_t, const Visits&) {}
+    RT_DEV void emit_any(uint32_t i, bool occluded, const Visits& vis) {
         if (!occluded) {
+            const uint32_t slot = pa.shadow_q[i];
             float4 c = pa.sh_c[slot];
-            if (c.w != 0.0f) {  // p_light > 0 (:234)
+            if (c.w != 0.0f) {  // p_light > 0 (path_integrator.rs:234)
                 float4 r = pa.rad[slot];
                 r.x += c.x;
                 r.y += c.y;
@@ -147,18 +152,21 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene sc, PathArrays pa, u
                 pa.rad[slot] = r;
             }
         }
+        n_int += vis.n_int;
+        n_tri += vis.n_tri;
     }
-    if (COUNT) {
-        unsigned long long a = vis.n_int, b = vis.n_tri;
-        for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_down(a, off);
-            b += __shfl_down(b, off);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&pa.visit[2], a);
-            atomicAdd(&pa.visit[3], b);
-        }
-    }
+};
+
+// path_integrator.rs:219: the shadow ray is tested over T_MIN..T_MAX, not up to the light.
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene sc, PathArrays pa, uint32_t n, uint32_t* work_counter,
+                                                     TraceTune tune, uint32_t* overflow, uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    ShadowIO io{pa, 0ull, 0ull};
+    trace_loop<true, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+                                                    lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    if (COUNT) add_visits(&pa.visit[2], io.n_int, io.n_tri);
 }
 
 // ---------------------------------------------------------------- shade
@@ -501,6 +509,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     pa.block_cnt = (uint32_t*)(base + o_bc);
     pa.block_off = (uint32_t*)(base + o_bo);
     pa.totals = (uint32_t*)(base + o_tot);
+    pa.work = pa.totals + 16;
     pa.visit = (unsigned long long*)(base + o_vis);
     RT_HIP(hipMemsetAsync(pa.visit, 0, 256, stream));
 
@@ -582,13 +591,14 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             }
             const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
             const int tgrid = (int)std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
+            RT_HIP(hipMemsetAsync(pa.work, 0, 8, stream));
             if ((rc = t_begin(1)) != RT_OK) return rc;
             if (count)
                 hipLaunchKernelGGL(k_extend<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                   pa.queue[cur], n, overflow, ostride);
+                                   pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
             else
                 hipLaunchKernelGGL(k_extend<false>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                   pa.queue[cur], n, overflow, ostride);
+                                   pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
             if ((rc = t_end(1)) != RT_OK) return rc;
             st.rays_closest += n;
             st.launches_extend += 1;
@@ -618,10 +628,10 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                 if ((rc = t_begin(3)) != RT_OK) return rc;
                 if (count)
                     hipLaunchKernelGGL(k_shadow<true>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
-                                       overflow, ostride);
+                                       pa.work + 1, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
                 else
                     hipLaunchKernelGGL(k_shadow<false>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                       n_shadow, overflow, ostride);
+                                       n_shadow, pa.work + 1, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
                 if ((rc = t_end(3)) != RT_OK) return rc;
                 st.rays_shadow += n_shadow;
                 st.launches_shadow += 1;
