@@ -272,6 +272,45 @@ int orc_render(const orc_scene* s, uint32_t width, uint32_t height, uint32_t spp
     return 0;
 }
 
+// The same loops for an arbitrary list of pixels (pixel = j*width + i): out[k*3..] = sum over the
+// samples of that pixel.  Used to check full-size GPU frames on a random subset of pixels.
+int orc_render_pixels(const orc_scene* s, uint32_t width, uint32_t height, uint32_t spp_first, uint32_t spp_count,
+                      uint32_t depth, uint64_t seed, const uint32_t* pixels, size_t n_pixels, uint32_t threads,
+                      float* out, orc_stats* stats) {
+    if (threads == 0) threads = 1;
+    std::atomic<size_t> next(0);
+    std::vector<RayCounters> rcs(threads);
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](uint32_t tid) {
+        RayCounters rc;
+        for (;;) {
+            size_t k = next.fetch_add(1);
+            if (k >= n_pixels) break;
+            uint32_t i = pixels[k] % width, j = pixels[k] / width;
+            Vec3D c = s->engine.render_pixel(i, j, width, height, spp_first, spp_count, depth, seed, &rc);
+            out[3 * k] = c.x; out[3 * k + 1] = c.y; out[3 * k + 2] = c.z;
+        }
+        rcs[tid] = rc;
+    };
+    if (threads == 1) worker(0);
+    else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < threads; ++t) pool.emplace_back(worker, t);
+        for (auto& th : pool) th.join();
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        for (auto& rc : rcs) {
+            stats->rays_closest += rc.closest;
+            stats->rays_shadow += rc.shadow;
+            stats->iterations += rc.iterations;
+        }
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stats->threads = threads;
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------- unit probes for the golden tests
 // AxisAlignedBoundingBox::new + hit (primitives.rs:257-261, :304-321). Returns 1 and *t for Some(t).
 int orc_aabb_hit(const float a[3], const float b[3], const float o[3], const float d[3], float t_min, float t_max,

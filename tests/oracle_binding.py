@@ -51,6 +51,10 @@ lib.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_u
                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(OrcStats)]
 
 
+lib.orc_render_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                  C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.POINTER(OrcStats)]
+
+
 def f3(v):
     return (C.c_float * 3)(*[float(np.float32(x)) for x in v])
 
@@ -124,6 +128,14 @@ class OracleScene:
         r0, r1 = rows if rows is not None else (0, height)
         lib.orc_render(self.handle, width, height, spp_first, spp, depth, seed, r0, r1, threads, out.ctypes.data,
                        C.byref(st))
+        return out, st
+
+    def render_pixels(self, width, height, pixels, spp, depth, seed=0, spp_first=0, threads=1):
+        px = np.ascontiguousarray(pixels, np.uint32)
+        out = np.zeros((len(px), 3), np.float32)
+        st = OrcStats()
+        lib.orc_render_pixels(self.handle, width, height, spp_first, spp, depth, seed, px.ctypes.data, len(px), threads,
+                              out.ctypes.data, C.byref(st))
         return out, st
 
     def __del__(self):
