@@ -40,7 +40,7 @@ def test_example_matches_python_host(ctx, tmp_path):
     assert r.stdout.startswith(header)
     got = np.array(r.stdout[len(header):].split(), dtype=np.uint8).reshape(h, w, 3)
 
-    scene = scenes.volumetric_sphere().build()
+    scene = api.Scene(scenes.volumetric_sphere())
     ctx.upload(scene)
     acc, _ = ctx.render(w, h, spp, depth, seed)
     want = api.tonemap_u8(acc, spp)
