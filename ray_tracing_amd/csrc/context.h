@@ -21,7 +21,15 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 constexpr int RT_BLOCK = 256;      // threads per workgroup in the traversal kernels (4 waves)
-constexpr int RT_STACK_LDS = 32;   // traversal-stack entries per lane kept in LDS (32 KiB/block)
+#ifndef RT_STACK_LDS_N
+#define RT_STACK_LDS_N 32
+#endif
+#ifndef RT_STACK_ANY_N
+#define RT_STACK_ANY_N RT_STACK_LDS_N
+#endif
+constexpr int RT_STACK_LDS = RT_STACK_LDS_N;  // traversal-stack entries per lane kept in LDS, closest-hit kernels (1 KiB/block each)
+constexpr int RT_STACK_ANY = RT_STACK_ANY_N;  // same for the any-hit kernels
+constexpr int RT_STACK_MIN = RT_STACK_LDS < RT_STACK_ANY ? RT_STACK_LDS : RT_STACK_ANY;
 constexpr int RT_TRACE_GRID = 2048;  // workgroups of the grid-stride trace kernels (8 per CU)
 
 struct DevBuf {

@@ -43,7 +43,7 @@ struct DObject {
 
 struct DScene {
     const DPair* pairs;
-    const float4* tris;  // 3 float4 per triangle
+    const float4* tris;  // 3 float4 per triangle; lives tri_off bytes after `pairs` in the same allocation
     const DObject* objects;
     const rt_material* materials;
     const rt_light* lights;
@@ -52,6 +52,7 @@ struct DScene {
     rt_camera_flat camera;
     int32_t initial_medium;
     uint32_t stack_need;  // deepest traversal stack any mesh of the scene can need
+    uint32_t tri_off;     // byte offset of tris from pairs (one allocation, < 4 GiB, 64 B of slack after it)
 };
 
 struct Hit {  // SurfaceIntersection (traits.rs:13-17) + ids
@@ -71,10 +72,15 @@ struct Visits {
 // in a per-lane global overflow strip (only trees deeper than STACK_LDS ever touch it).
 template <int STACK_LDS, int BLOCK>
 struct Stack {
-    uint32_t* lds;        // &shared[0][threadIdx.x]
+    // The LDS half is addressed through an explicit address-space-3 pointer: with two generic
+    // pointers the compiler merges pop() into ONE flat_load of a selected address, which sends every
+    // LDS pop through the texture-address path and makes it wait on both memory counters.
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* lds;         // &shared[0][threadIdx.x]
     uint32_t* overflow;   // &overflow[global lane], stride = overflow_stride
     uint32_t overflow_stride;
     int sp;
+    RT_DEV void set_lds(uint32_t* p) { lds = (lds_u32*)p; }
     RT_DEV void push(uint32_t v) {
         if (sp < STACK_LDS) lds[sp * BLOCK] = v;
         else overflow[(size_t)(sp - STACK_LDS) * overflow_stride] = v;
@@ -82,7 +88,10 @@ struct Stack {
     }
     RT_DEV uint32_t pop() {
         --sp;
-        return sp < STACK_LDS ? lds[sp * BLOCK] : overflow[(size_t)(sp - STACK_LDS) * overflow_stride];
+        uint32_t v;
+        if (sp < STACK_LDS) v = lds[sp * BLOCK];
+        else v = overflow[(size_t)(sp - STACK_LDS) * overflow_stride];
+        return v;
     }
 };
 

@@ -15,11 +15,24 @@
 #pragma once
 #include "device_scene.h"
 
+
 namespace rtd {
 
+#if RT_TRACE_STATS  // diagnostics build only (scripts/build_variant.sh stats -DRT_TRACE_STATS=1)
+static __device__ unsigned long long g_trace_stats[32];
+#define RT_STAT(i, v) s_stat[i] += (v)
+#else
+#define RT_STAT(i, v)
+#endif
+
 // Launch-time tuning of the wave scheduler (uniform kernel argument).
+constexpr uint32_t WORK_MAX_SEG = 64;     // work counters per launch
+constexpr uint32_t WORK_STRIDE = 32;      // u32 between counters: one 128-byte line each
+constexpr uint32_t WORK_U32 = WORK_MAX_SEG * WORK_STRIDE;
 struct TraceTune {
-    uint32_t chunk;       // rays a wave takes from the global work counter per atomic
+    uint32_t chunk;       // rays a wave takes from a work counter per atomic
+    uint32_t n_seg;       // the queue is split into n_seg contiguous segments, one counter each
+    uint32_t seg_len;     // rays per segment (multiple of chunk)
     uint32_t refill_min;  // idle lanes that trigger a refill
     uint32_t w_adv, w_node, w_leaf;  // phase weights: each loop iteration runs the ONE phase with the largest
                                      // (lanes waiting for it) x weight
@@ -34,22 +47,65 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
     return *reinterpret_cast<const float4*>(static_cast<const char*>(base) + byte_off);
 }
 
+#ifndef RT_COOP
+#define RT_COOP 0
+#endif
+// Quad-cooperative record fetch.  Measured on MI355X (scripts/microbench/gather64.hip): a wave in
+// which every lane reads its own 64-byte record with 4 x global_load_dwordx4 is limited by the
+// vector L1's divergent-access rate (one lane-line per clock: 99 G records/s chip-wide however small
+// the table), and the traversal ran at 76 G records/s -- against THAT ceiling, not HBM's.  When the 4
+// lanes of a quad read the 4 x 16 bytes of ONE record per instruction, each instruction touches 16
+// lines instead of 64 and the same gather runs at 230-300 G records/s.  The pieces are handed to
+// their owner through a per-lane 80-byte LDS slot (80, not 64: the slots of the 8 lanes served by
+// one LDS pass then fall on disjoint banks).
+typedef float f4v __attribute__((ext_vector_type(4)));  // native vector: assignable through an address-space pointer
+typedef __attribute__((address_space(3))) f4v lds_f4;
+RT_DEV f4v to_v(float4 a) { return f4v{a.x, a.y, a.z, a.w}; }
+RT_DEV float4 to_f4(f4v a) { return make_float4(a.x, a.y, a.z, a.w); }
+constexpr uint32_t STAGE_F4 = 5;  // float4 per lane slot
+template <int M>
+RT_DEV uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, M * 0x55, 0xf, 0xf, true);
+}
+// every lane of the wave must call this (uniform control flow); off = this lane's record offset
+RT_DEV void coop_fetch64(const void* base, uint32_t off, lds_f4* stage_wave, uint32_t lane, float4* r0, float4* r1,
+                         float4* r2, float4* r3) {
+    const uint32_t j16 = (lane & 3u) << 4, q = lane & ~3u, j = lane & 3u;
+    const float4 p0 = ld16(base, quad_bcast<0>(off) + j16), p1 = ld16(base, quad_bcast<1>(off) + j16),
+                 p2 = ld16(base, quad_bcast<2>(off) + j16), p3 = ld16(base, quad_bcast<3>(off) + j16);
+    stage_wave[(q + 0u) * STAGE_F4 + j] = to_v(p0);
+    stage_wave[(q + 1u) * STAGE_F4 + j] = to_v(p1);
+    stage_wave[(q + 2u) * STAGE_F4 + j] = to_v(p2);
+    stage_wave[(q + 3u) * STAGE_F4 + j] = to_v(p3);
+    __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order; this only pins the code order
+    *r0 = to_f4(stage_wave[lane * STAGE_F4 + 0u]);
+    *r1 = to_f4(stage_wave[lane * STAGE_F4 + 1u]);
+    *r2 = to_f4(stage_wave[lane * STAGE_F4 + 2u]);
+    *r3 = to_f4(stage_wave[lane * STAGE_F4 + 3u]);
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool ANY, bool COUNT, int STACK_LDS, int BLOCK, class IO>
 RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
                        float t_max_in,
-                       uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride) {
+                       uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride, float4* lds_stage = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64u - lane));
     Stack<STACK_LDS, BLOCK> st;
-    st.lds = lds;
+    st.set_lds(lds);
     st.overflow = overflow;
     st.overflow_stride = overflow_stride;
     st.sp = 0;
+    // lds_stage: RT_BLOCK * STAGE_F4 float4 of LDS; this wave's 64 slots
+#if RT_COOP
+    lds_f4* const stage_wave = (lds_f4*)lds_stage + (threadIdx.x & ~63u) * STAGE_F4;
+#endif
 
     const uint32_t refill_min = tune.refill_min, chunk = tune.chunk;
     uint32_t ray = RAY_NONE;
     bool more = true;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
+    uint32_t seg = blockIdx.x % tune.n_seg, seg_tried = 0;  // wave-uniform
     V3 wo = v3(0, 0, 0), wd = v3(0, 0, 0);            // world-space ray
     V3 o = wo, d = wd, inv = wd;                      // object-space ray of the current object
     float nr = 1.0f;                                  // |M^-1 d|^-1 of the current object
@@ -62,26 +118,35 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     uint32_t hit_tri = 0, hit_ff = 0;
     bool obj_hit = false, fresh = false;
     Visits vis = {0, 0};
+#if RT_TRACE_STATS
+    unsigned long long s_stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     for (;;) {
         // ---------------------------------------------------------------- refill idle lanes
-        // The wave owns a pool [pool_next, pool_end) of consecutive ray indices taken from the
-        // global counter `chunk` at a time (one atomic per chunk; the host sizes it so that every
-        // wave of the launch comes back for work several times -- a tail of full pools is a static split again); idle lanes draw from it.
+        // The wave owns a pool [pool_next, pool_end) of consecutive ray indices; idle lanes draw
+        // from it, and it is restocked `chunk` rays at a time from the launch's work counters.
         if (more) {
             const bool idle = ray == RAY_NONE;
             const unsigned long long m = __ballot(idle);
             const uint32_t n_idle = (uint32_t)__popcll(m);
             if (n_idle >= refill_min || (n_idle > 0 && __ballot(!idle) == 0ull)) {
-                if (pool_next == pool_end) {
+                // A wave draws `chunk` consecutive rays at a time from the counter of its current
+                // segment (home segment = block index mod n_seg; the next one when that is drained).
+                // One counter for the whole launch was the bottleneck of the first version: device-
+                // scope atomics on one address complete at the memory side, about one per 15 ns, and
+                // a frame needs 4.4 M of them at chunk 64 (profiles/r01/tuning.md).
+                while (pool_next == pool_end && more) {
                     uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(work_counter, chunk);
+                    if (lane == 0) b = atomicAdd(work_counter + seg * WORK_STRIDE, chunk);
                     b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                    if (b >= n) {
-                        more = false;
+                    const uint32_t seg_begin = seg * tune.seg_len;
+                    if (b < tune.seg_len && seg_begin + b < n) {
+                        pool_next = seg_begin + b;
+                        pool_end = min(min(pool_next + chunk, seg_begin + tune.seg_len), n);
                     } else {
-                        pool_next = b;
-                        pool_end = min(b + chunk, n);
+                        seg = seg + 1u == tune.n_seg ? 0u : seg + 1u;
+                        if (++seg_tried == tune.n_seg) more = false;
                     }
                 }
                 if (more) {
@@ -116,6 +181,19 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         const bool run_node = s_node >= s_leaf && s_node >= s_adv;
         const bool run_leaf = !run_node && s_leaf >= s_adv;
         const bool run_adv = !run_node && !run_leaf;
+#if RT_TRACE_STATS
+        if (lane == 0) {
+            const uint32_t na = s_adv / tune.w_adv, nn = s_node / tune.w_node, nl = s_leaf / tune.w_leaf;
+            const uint32_t run = run_node ? nn : run_leaf ? nl : na;
+            RT_STAT(0, 1);                         // iterations
+            RT_STAT(1, run);                       // lanes that advance
+            RT_STAT(2, na + nn + nl - run);        // lanes waiting for another phase
+            RT_STAT(more ? 3 : 4, 64u - na - nn - nl);  // idle lanes (queue not empty / draining)
+            RT_STAT(5, run_node ? 1 : 0);
+            RT_STAT(6, run_leaf ? 1 : 0);
+            RT_STAT(7, run_adv ? 1 : 0);
+        }
+#endif
 
         // ---------------------------------------------------------------- A: next object
         if (run_adv) {
@@ -199,10 +277,16 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
 
         // ---------------------------------------------------------------- B: internal node
         if (run_node) {
+#if RT_COOP
+            float4 a0, a1, b0, b1;
+            coop_fetch64(sc.pairs, isnode ? cur << 6 : 0u, stage_wave, lane, &a0, &a1, &b0, &b1);
+            if (isnode) {
+#else
             if (isnode) {
                 const uint32_t off = cur << 6;
                 float4 a0 = ld16(sc.pairs, off), a1 = ld16(sc.pairs, off + 16u), b0 = ld16(sc.pairs, off + 32u),
                        b1 = ld16(sc.pairs, off + 48u);
+#endif
                 if (COUNT) vis.n_int += 1;
                 float lo1[3] = {a0.x, a0.y, a0.z}, hi1[3] = {a0.w, a1.x, a1.y};
                 float lo2[3] = {b0.x, b0.y, b0.z}, hi2[3] = {b0.w, b1.x, b1.y};
@@ -254,6 +338,10 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             }
         }
     }
+#if RT_TRACE_STATS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_trace_stats[(ANY ? 8 : 0) + i], s_stat[i]);
+#endif
 }
 
 }  // namespace rtd

@@ -35,22 +35,41 @@ int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes) {
 }
 
 TraceTune rt_trace_tune(size_t n, int grid) {
-    // Defaults from sweeps on MI355X (profiles/r01/tuning.md); RT_TUNE="chunk,refill,w_adv,w_node,w_leaf"
-    // overrides them for experiments.
-    static TraceTune t = {0, 0, 0, 0, 0};
-    if (t.chunk == 0) {
-        TraceTune d = {64, 16, 1, 2, 3};
+    // Defaults from sweeps on MI355X (profiles/r01/tuning.md);
+    // RT_TUNE="chunk,refill,w_adv,w_node,w_leaf,max_seg" overrides them for experiments.
+    static unsigned v[6] = {0, 0, 0, 0, 0, 0};
+    static bool have_env = false;
+    if (v[1] == 0) {
+        unsigned d[6] = {0, 16, 1, 2, 3, WORK_MAX_SEG};
         const char* e = getenv("RT_TUNE");
         if (e) {
-            unsigned v[5] = {d.chunk, d.refill_min, d.w_adv, d.w_node, d.w_leaf};
-            sscanf(e, "%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4]);
-            d = {v[0] ? v[0] : 64u, v[1] ? (v[1] > 64u ? 64u : v[1]) : 1u, v[2], v[3], v[4]};
-            if (d.w_adv + d.w_node + d.w_leaf == 0 || !d.w_adv || !d.w_node || !d.w_leaf) d = {d.chunk, d.refill_min, 1, 2, 3};
+            sscanf(e, "%u,%u,%u,%u,%u,%u", &d[0], &d[1], &d[2], &d[3], &d[4], &d[5]);
+            have_env = true;
         }
-        t = d;
+        if (d[0] > 4096) d[0] = 0;
+        if (d[1] == 0 || d[1] > 64) d[1] = 16;
+        if (!d[2] || !d[3] || !d[4]) d[2] = 1, d[3] = 2, d[4] = 3;
+        if (d[5] == 0 || d[5] > WORK_MAX_SEG) d[5] = WORK_MAX_SEG;
+        for (int i = 0; i < 6; ++i) v[i] = d[i];
     }
-    (void)n;
-    (void)grid;
+    (void)have_env;
+    TraceTune t;
+    // chunk: 128 rays per atomic on frame-sized launches, 64 on small ones (finer tail balance)
+    t.chunk = v[0] ? v[0] : (n >= ((size_t)16 << 20) ? 128u : 64u);
+    t.refill_min = v[1];
+    t.w_adv = v[2];
+    t.w_node = v[3];
+    t.w_leaf = v[4];
+    // segments: at most max_seg, each at least 2048 chunks long (a drained segment costs every wave
+    // one probe), never more than the launch has blocks
+    uint64_t seg = n / ((uint64_t)t.chunk * 2048);
+    if (seg > v[5]) seg = v[5];
+    if (seg > (uint64_t)grid) seg = (uint64_t)grid;
+    if (seg < 1) seg = 1;
+    t.n_seg = (uint32_t)seg;
+    uint64_t len = (n + seg - 1) / seg;
+    len = (len + t.chunk - 1) / t.chunk * t.chunk;
+    t.seg_len = (uint32_t)len;
     return t;
 }
 
@@ -85,10 +104,16 @@ template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceIO io, uint32_t n, float t_min, float t_max,
                                                     uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                     uint32_t overflow_stride) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    constexpr int STACK = ANY ? RT_STACK_ANY : RT_STACK_LDS;
+    __shared__ uint32_t lds_stack[STACK * RT_BLOCK];
+#if RT_COOP
+    __shared__ float4 lds_stage[RT_BLOCK * rtd::STAGE_F4];
+#else
+    float4* const lds_stage = nullptr;
+#endif
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    trace_loop<ANY, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, t_min, t_max, lds_stack + threadIdx.x,
-                                                   overflow + gtid, overflow_stride);
+    trace_loop<ANY, COUNT, STACK, RT_BLOCK>(sc, io, n, work_counter, tune, t_min, t_max, lds_stack + threadIdx.x,
+                                            overflow + gtid, overflow_stride, lds_stage);
 }
 
 // ---------------------------------------------------------------- helpers
@@ -368,8 +393,20 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
         if (bytes) RT_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         return RT_OK;
     };
-    if ((rc = up(ctx->pairs, pairs.data(), pairs.size() * sizeof(DPair))) != RT_OK) return rc;
-    if ((rc = up(ctx->tris, tris.data(), tris.size() * sizeof(float4))) != RT_OK) return rc;
+    // child pairs and triangles share ONE allocation so that the traversal step can fetch either with
+    // the same uniform base + 32-bit lane offset; 64 B of slack lets a leaf lane issue the 4th 16-B
+    // load of the common 64-B fetch shape.
+    const size_t pair_bytes = pairs.size() * sizeof(DPair), tri_bytes = tris.size() * sizeof(float4);
+    const size_t tri_off = (pair_bytes + 255) & ~(size_t)255;
+    if (tri_off + tri_bytes + 64 >= (1ull << 32)) {
+        rth::set_error("rt_upload_scene: BVH nodes + triangles exceed the 4 GiB geometry window");
+        return RT_ERR_LIMIT;
+    }
+    if ((rc = ctx->pairs.ensure(tri_off + tri_bytes + 64)) != RT_OK) return rc;
+    RT_HIP(hipMemsetAsync((char*)ctx->pairs.p + tri_off + tri_bytes, 0, 64, ctx->stream));
+    if (pair_bytes) RT_HIP(hipMemcpyAsync(ctx->pairs.p, pairs.data(), pair_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (tri_bytes)
+        RT_HIP(hipMemcpyAsync((char*)ctx->pairs.p + tri_off, tris.data(), tri_bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = up(ctx->objects, objs.data(), objs.size() * sizeof(DObject))) != RT_OK) return rc;
     if ((rc = up(ctx->materials, s->materials, s->n_materials * sizeof(rt_material))) != RT_OK) return rc;
     if ((rc = up(ctx->lights, s->lights, s->n_lights * sizeof(rt_light))) != RT_OK) return rc;
@@ -378,7 +415,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
 
     DScene& d = ctx->scene;
     d.pairs = (const DPair*)ctx->pairs.p;
-    d.tris = (const float4*)ctx->tris.p;
+    d.tris = (const float4*)((const char*)ctx->pairs.p + tri_off);
+    d.tri_off = (uint32_t)tri_off;
     d.objects = (const DObject*)ctx->objects.p;
     d.materials = (const rt_material*)ctx->materials.p;
     d.lights = (const rt_light*)ctx->lights.p;
@@ -390,7 +428,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
     d.camera = s->camera;
     d.initial_medium = s->initial_medium == RT_MEDIUM_AUTO ? RT_MEDIUM_NONE : s->initial_medium;
     d.stack_need = stack_need;
-    ctx->overflow_levels = stack_need > (uint32_t)RT_STACK_LDS ? stack_need - RT_STACK_LDS : 0;
+    ctx->overflow_levels = stack_need > (uint32_t)RT_STACK_MIN ? stack_need - RT_STACK_MIN : 0;
     ctx->has_scene = true;
 
     if (s->initial_medium == RT_MEDIUM_AUTO) {
@@ -473,8 +511,8 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
     int grid = trace_grid(n);
     size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
-    if ((rc = ctx->counters.ensure(256)) != RT_OK) return rc;
-    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, 4, ctx->stream));
+    if ((rc = ctx->counters.ensure(WORK_U32 * 4)) != RT_OK) return rc;
+    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, WORK_U32 * 4, ctx->stream));
     bool count = dh.n_int || dh.n_tri;
     TraceIO io{dr, dh, nullptr};
     RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -523,8 +561,8 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
     int grid = trace_grid(n);
     size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
-    if ((rc = ctx->counters.ensure(256)) != RT_OK) return rc;
-    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, 4, ctx->stream));
+    if ((rc = ctx->counters.ensure(WORK_U32 * 4)) != RT_OK) return rc;
+    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, WORK_U32 * 4, ctx->stream));
     rt_hits dh;
     memset(&dh, 0, sizeof dh);
     dh.n_int = d_ni;

@@ -49,7 +49,7 @@ struct PathArrays {      // SoA over slots
     uint32_t* block_cnt; // [2][blocks]: alive, shadow totals per shade block
     uint32_t* block_off; // [2][blocks]: exclusive scan
     uint32_t* totals;    // [0] next live count, [1] shadow count
-    uint32_t* work;      // [0] extend work counter, [1] shadow work counter (zeroed per launch)
+    uint32_t* work;      // extend work counters [0, WORK_U32), shadow work counters [WORK_U32, 2*WORK_U32) (zeroed per iteration)
     unsigned long long* visit; // [0] n_int extend, [1] n_tri extend, [2] n_int shadow, [3] n_tri shadow
 };
 
@@ -122,10 +122,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene sc, PathArrays pa, c
                                                      uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                      uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+#if RT_COOP
+    __shared__ float4 lds_stage[RT_BLOCK * rtd::STAGE_F4];
+#else
+    float4* const lds_stage = nullptr;
+#endif
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     ExtendIO io{pa, queue, 0ull, 0ull};
     trace_loop<false, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                     lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+                                                     lds_stack + threadIdx.x, overflow + gtid, overflow_stride, lds_stage);
     if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
 }
 
@@ -161,11 +166,16 @@ struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds it
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene sc, PathArrays pa, uint32_t n, uint32_t* work_counter,
                                                      TraceTune tune, uint32_t* overflow, uint32_t overflow_stride) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t lds_stack[RT_STACK_ANY * RT_BLOCK];
+#if RT_COOP
+    __shared__ float4 lds_stage[RT_BLOCK * rtd::STAGE_F4];
+#else
+    float4* const lds_stage = nullptr;
+#endif
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     ShadowIO io{pa, 0ull, 0ull};
-    trace_loop<true, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                    lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    trace_loop<true, COUNT, RT_STACK_ANY, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+                                                    lds_stack + threadIdx.x, overflow + gtid, overflow_stride, lds_stage);
     if (COUNT) add_visits(&pa.visit[2], io.n_int, io.n_tri);
 }
 
@@ -497,7 +507,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
            o_meta = carve(P * 16), o_hit_a = carve(P * 16), o_hit_b = carve(P * 8), o_sh_o = carve(P * 16),
            o_sh_d = carve(P * 16), o_sh_c = carve(P * 16), o_q0 = carve(P * 4), o_q1 = carve(P * 4),
            o_sq = carve(P * 4), o_qf = carve(P * 4), o_bc = carve((size_t)max_blocks * 8),
-           o_bo = carve((size_t)max_blocks * 8), o_tot = carve(256), o_vis = carve(256);
+           o_bo = carve((size_t)max_blocks * 8), o_tot = carve(256), o_vis = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
     int rc = ctx->path_state.ensure(off);
     if (rc != RT_OK) return rc;
     char* base = (char*)ctx->path_state.p;
@@ -519,7 +529,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     pa.block_cnt = (uint32_t*)(base + o_bc);
     pa.block_off = (uint32_t*)(base + o_bo);
     pa.totals = (uint32_t*)(base + o_tot);
-    pa.work = pa.totals + 16;
+    pa.work = (uint32_t*)(base + o_work);
     pa.visit = (unsigned long long*)(base + o_vis);
     RT_HIP(hipMemsetAsync(pa.visit, 0, 256, stream));
 
@@ -601,7 +611,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             }
             const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
             const int tgrid = (int)std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
-            RT_HIP(hipMemsetAsync(pa.work, 0, 8, stream));
+            RT_HIP(hipMemsetAsync(pa.work, 0, 2 * rtd::WORK_U32 * 4, stream));
             if ((rc = t_begin(1)) != RT_OK) return rc;
             if (count)
                 hipLaunchKernelGGL(k_extend<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
@@ -638,10 +648,10 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                 if ((rc = t_begin(3)) != RT_OK) return rc;
                 if (count)
                     hipLaunchKernelGGL(k_shadow<true>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
-                                       pa.work + 1, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
+                                       pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
                 else
                     hipLaunchKernelGGL(k_shadow<false>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                       n_shadow, pa.work + 1, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
+                                       n_shadow, pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
                 if ((rc = t_end(3)) != RT_OK) return rc;
                 st.rays_shadow += n_shadow;
                 st.launches_shadow += 1;
@@ -680,3 +690,14 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     if (stats) *stats = st;
     return RT_OK;
 }
+
+#if RT_TRACE_STATS
+extern "C" int rt_debug_trace_stats(unsigned long long* out32, int reset) {
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(rtd::g_trace_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_stats), z, sizeof z) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
