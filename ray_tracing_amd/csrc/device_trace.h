@@ -50,7 +50,8 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
 #ifndef RT_COOP
 #define RT_COOP 0
 #endif
-// Quad-cooperative record fetch.  Measured on MI355X (scripts/microbench/gather64.hip): a wave in
+// Quad-cooperative record fetch (RT_COOP=1; compiled out by default -- see the end of this comment).
+// Measured on MI355X (scripts/microbench/gather64.hip): a wave in
 // which every lane reads its own 64-byte record with 4 x global_load_dwordx4 is limited by the
 // vector L1's divergent-access rate (one lane-line per clock: 99 G records/s chip-wide however small
 // the table), and the traversal ran at 76 G records/s -- against THAT ceiling, not HBM's.  When the 4
@@ -58,6 +59,10 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
 // lines instead of 64 and the same gather runs at 230-300 G records/s.  The pieces are handed to
 // their owner through a per-lane 80-byte LDS slot (80, not 64: the slots of the 8 lanes served by
 // one LDS pass then fall on disjoint banks).
+// In the traversal loop the cooperative fetch costs the same whether 10 or 60 lanes need a record,
+// while the per-lane fetch is charged per active lane; at the ~45-50 % of lanes that advance per
+// iteration here the two came out within 5 % of each other (extend 54.8 ms cooperative vs 52.5 ms
+// per-lane, profiles/r01/tuning.md), so the simpler per-lane path is the default.
 typedef float f4v __attribute__((ext_vector_type(4)));  // native vector: assignable through an address-space pointer
 typedef __attribute__((address_space(3))) f4v lds_f4;
 RT_DEV f4v to_v(float4 a) { return f4v{a.x, a.y, a.z, a.w}; }
@@ -174,21 +179,36 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         const bool adv = ray != RAY_NONE && cur == REF_ADVANCE;
         const bool isnode = ray != RAY_NONE && (cur & LEAF_BIT) == 0u;
         const bool isleaf = ray != RAY_NONE && (cur & LEAF_BIT) != 0u && cur != REF_ADVANCE;
-        const uint32_t s_adv = (uint32_t)__popcll(__ballot(adv)) * tune.w_adv;
-        const uint32_t s_node = (uint32_t)__popcll(__ballot(isnode)) * tune.w_node;
-        const uint32_t s_leaf = (uint32_t)__popcll(__ballot(isleaf)) * tune.w_leaf;
-        if ((s_adv | s_node | s_leaf) == 0u) break;
+        const uint32_t n_adv = (uint32_t)__popcll(__ballot(adv)), n_node = (uint32_t)__popcll(__ballot(isnode)),
+                       n_leaf = (uint32_t)__popcll(__ballot(isleaf));
+        if ((n_adv | n_node | n_leaf) == 0u) break;
+#if RT_COOP
+        // Cooperative mode: ONE 64-byte fetch per lane per iteration serves node lanes (child pair)
+        // and leaf lanes (triangle) alike -- its cost does not depend on how many lanes use it --
+        // so every lane inside a tree moves on each traversal iteration.  The triangle arithmetic
+        // (the expensive half) is deferred until enough leaf lanes have gathered; a waiting leaf
+        // lane simply receives its triangle again.
+        const bool run_trav = (n_node + n_leaf) * tune.w_node >= n_adv * tune.w_adv && (n_node + n_leaf) > 0u;
+        const bool run_adv = !run_trav;
+        const bool run_tri = run_trav && n_leaf * tune.w_leaf >= n_node;
+#else
+        const uint32_t s_adv = n_adv * tune.w_adv, s_node = n_node * tune.w_node, s_leaf = n_leaf * tune.w_leaf;
         const bool run_node = s_node >= s_leaf && s_node >= s_adv;
         const bool run_leaf = !run_node && s_leaf >= s_adv;
         const bool run_adv = !run_node && !run_leaf;
+#endif
 #if RT_TRACE_STATS
         if (lane == 0) {
-            const uint32_t na = s_adv / tune.w_adv, nn = s_node / tune.w_node, nl = s_leaf / tune.w_leaf;
-            const uint32_t run = run_node ? nn : run_leaf ? nl : na;
+#if RT_COOP
+            const uint32_t run = run_trav ? n_node + (run_tri ? n_leaf : 0u) : n_adv;
+            const bool run_node = run_trav, run_leaf = run_tri;
+#else
+            const uint32_t run = run_node ? n_node : run_leaf ? n_leaf : n_adv;
+#endif
             RT_STAT(0, 1);                         // iterations
             RT_STAT(1, run);                       // lanes that advance
-            RT_STAT(2, na + nn + nl - run);        // lanes waiting for another phase
-            RT_STAT(more ? 3 : 4, 64u - na - nn - nl);  // idle lanes (queue not empty / draining)
+            RT_STAT(2, n_adv + n_node + n_leaf - run);  // lanes waiting for another phase
+            RT_STAT(more ? 3 : 4, 64u - n_adv - n_node - n_leaf);  // idle lanes (queue not empty / draining)
             RT_STAT(5, run_node ? 1 : 0);
             RT_STAT(6, run_leaf ? 1 : 0);
             RT_STAT(7, run_adv ? 1 : 0);
@@ -235,6 +255,19 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     const float t_lim = ANY ? t_max_in : best_t;
                     if (ob.kind == RT_SURF_MESH) {
                         inv = v3(recip(d.x), recip(d.y), recip(d.z));
+                        // Skip a mesh whose ROOT box the ray misses.  The reference never tests the
+                        // root (bvh.rs:252) and would fetch its child pair and miss both children;
+                        // that outcome is certain: a child box lies inside the root box bound for
+                        // bound (both are min/max over subsets of the same vertices) and every step
+                        // of AABB::hit is monotone in the bounds, so a ray that fails the root test
+                        // fails both child tests with the same arithmetic.  No triangle is tested in
+                        // either case: the result is identical, one node visit and two phase changes
+                        // cheaper.  Not applied when counting visits (those stay the reference's) or
+                        // when the root is itself a leaf.
+                        if (!COUNT && (ob.root_ref & LEAF_BIT) == 0u) {
+                            float t_entry;
+                            if (!aabb_hit(&ob.surf[0], &ob.surf[3], o, inv, t_min, t_lim, &t_entry)) continue;
+                        }
                         tmax = t_lim;
                         cur = ob.root_ref;
                         st.sp = 0;
@@ -275,18 +308,65 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             }
         }
 
+#if RT_COOP
+        // ---------------------------------------------------------------- B+C: traversal step
+        if (run_trav) {
+            const uint32_t k = cur & ~LEAF_BIT;
+            const uint32_t off = isnode ? cur << 6 : isleaf ? sc.tri_off + k * 48u : 0u;
+            float4 a0, a1, b0, b1;
+            coop_fetch64(sc.pairs, off, stage_wave, lane, &a0, &a1, &b0, &b1);
+            if (isnode) {
+                if (COUNT) vis.n_int += 1;
+                float lo1[3] = {a0.x, a0.y, a0.z}, hi1[3] = {a0.w, a1.x, a1.y};
+                float lo2[3] = {b0.x, b0.y, b0.z}, hi2[3] = {b0.w, b1.x, b1.y};
+                const uint32_t ref1 = __float_as_uint(a1.z), ref2 = __float_as_uint(b1.z);
+                float t1, t2;
+                const bool h1 = aabb_hit(lo1, hi1, o, inv, t_min, tmax, &t1);
+                const bool h2 = aabb_hit(lo2, hi2, o, inv, t_min, tmax, &t2);
+                if (h1 && h2) {  // bvh.rs:287-295: far pushed, near next; near = child1 unless t1 > t2
+                    const bool swap = t1 > t2;
+                    st.push(swap ? ref1 : ref2);
+                    cur = swap ? ref2 : ref1;
+                } else if (h1) {
+                    cur = ref1;
+                } else if (h2) {
+                    cur = ref2;
+                } else {
+                    cur = st.sp == 0 ? REF_ADVANCE : st.pop();
+                }
+            }
+            if (run_tri) {
+                if (isleaf) {  // one primitive of the leaf per step, in `indices` order (bvh.rs:256-266)
+                    if (COUNT) vis.n_tri += 1;
+                    float t, det;
+                    bool done = false;
+                    if (tri_hit(v3(a0.x, a0.y, a0.z), v3(a1.x, a1.y, a1.z), v3(b0.x, b0.y, b0.z), o, d, t_min, tmax, &t,
+                                &det)) {
+                        if (ANY) {
+                            io.emit_any(ray, true, vis);
+                            ray = RAY_NONE;
+                            done = true;
+                        } else {
+                            tmax = t;
+                            hit_tri = k;
+                            hit_ff = det > 0.0f;
+                            obj_hit = true;
+                        }
+                    }
+                    if (!done) {
+                        if (__float_as_uint(a1.w)) cur = st.sp == 0 ? REF_ADVANCE : st.pop();
+                        else cur = LEAF_BIT | (k + 1u);
+                    }
+                }
+            }
+        }
+#else
         // ---------------------------------------------------------------- B: internal node
         if (run_node) {
-#if RT_COOP
-            float4 a0, a1, b0, b1;
-            coop_fetch64(sc.pairs, isnode ? cur << 6 : 0u, stage_wave, lane, &a0, &a1, &b0, &b1);
-            if (isnode) {
-#else
             if (isnode) {
                 const uint32_t off = cur << 6;
                 float4 a0 = ld16(sc.pairs, off), a1 = ld16(sc.pairs, off + 16u), b0 = ld16(sc.pairs, off + 32u),
                        b1 = ld16(sc.pairs, off + 48u);
-#endif
                 if (COUNT) vis.n_int += 1;
                 float lo1[3] = {a0.x, a0.y, a0.z}, hi1[3] = {a0.w, a1.x, a1.y};
                 float lo2[3] = {b0.x, b0.y, b0.z}, hi2[3] = {b0.w, b1.x, b1.y};
@@ -337,6 +417,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                 if (!done) cur = st.sp == 0 ? REF_ADVANCE : st.pop();
             }
         }
+#endif
     }
 #if RT_TRACE_STATS
     if (lane == 0)

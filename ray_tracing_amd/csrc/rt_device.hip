@@ -362,6 +362,15 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
             o.root_ref = root_ref[f.bvh];
         }
         memcpy(o.surf, f.surf, 9 * sizeof(float));
+        if (f.surface_kind == RT_SURF_MESH) {
+            // bounds of the mesh's root node (nodes[0] of bvh.rs:60-66): the reference never tests
+            // them, the traversal uses them to skip a mesh the ray cannot enter (device_trace.h)
+            const rt_bvh_flat& b = s->bvhs[f.bvh];
+            for (int a = 0; a < 3; ++a) {
+                o.surf[a] = s->node_lower[3 * (size_t)b.node_offset + a];
+                o.surf[3 + a] = s->node_upper[3 * (size_t)b.node_offset + a];
+            }
+        }
         if (f.surface_kind == RT_SURF_TRIANGLE) {
             for (int a = 0; a < 3; ++a) {
                 o.surf[3 + a] = f.surf[3 + a] - f.surf[a];
