@@ -20,9 +20,19 @@ void set_error(const char* fmt, ...);
         }                                                                                       \
     } while (0)
 
+// Occupancy target of the traversal kernels: the compiler keeps their VGPR use within what lets this
+// many waves share a SIMD (512 VGPRs / waves, 8-register granules).
+#ifndef RT_WAVES_EU
+#define RT_WAVES_EU 5
+#endif
+#ifndef RT_WAVES_EU_ANY
+#define RT_WAVES_EU_ANY 6  // the any-hit loop needs fewer registers: 6 waves fit without spills
+#endif
+#define RT_TRACE_ATTR __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU)))
+#define RT_TRACE_ATTR_ANY __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_ANY)))
 constexpr int RT_BLOCK = 256;      // threads per workgroup in the traversal kernels (4 waves)
 #ifndef RT_STACK_LDS_N
-#define RT_STACK_LDS_N 32
+#define RT_STACK_LDS_N 24
 #endif
 #ifndef RT_STACK_ANY_N
 #define RT_STACK_ANY_N RT_STACK_LDS_N

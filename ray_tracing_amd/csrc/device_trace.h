@@ -111,17 +111,16 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     bool more = true;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
     uint32_t seg = blockIdx.x % tune.n_seg, seg_tried = 0;  // wave-uniform
-    V3 wo = v3(0, 0, 0), wd = v3(0, 0, 0);            // world-space ray
-    V3 o = wo, d = wd, inv = wd;                      // object-space ray of the current object
+    V3 wo = v3(0, 0, 0), wd = wo;                     // world-space ray
+    V3 o = wo, d = wo, inv = wo;                      // object-space ray of the current object
     float nr = 1.0f;                                  // |M^-1 d|^-1 of the current object
     uint32_t obj = 0;
     uint32_t cur = REF_ADVANCE;
     float tmax = 0.0f;                                // running t_max inside the current object
     float best_t = 0.0f;                              // Engine::hit's shrinking t_max (world)
-    V3 best_n = wo;
-    uint32_t best_meta = RT_MISS, best_prim = RT_MISS;
-    uint32_t hit_tri = 0, hit_ff = 0;
-    bool obj_hit = false, fresh = false;
+    bool got = false;                                 // a hit has been recorded through io.hit()
+    uint32_t hit_tri = 0;
+    bool hit_ff = false, obj_hit = false, fresh = false;
     Visits vis = {0, 0};
 #if RT_TRACE_STATS
     unsigned long long s_stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -161,7 +160,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                         ray = pool_next + rank;
                         io.load(ray, &wo, &wd);
                         best_t = t_max_in;
-                        best_meta = RT_MISS;
+                        got = false;
                         cur = REF_ADVANCE;
                         obj_hit = false;
                         fresh = true;
@@ -229,9 +228,8 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                         nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
                     }
                     best_t = t;
-                    best_n = nrm;
-                    best_meta = obj | (hit_ff << 31);
-                    best_prim = __float_as_uint(q0.w);
+                    got = true;
+                    io.hit(ray, t, nrm, obj | (hit_ff ? 0x80000000u : 0u), __float_as_uint(q0.w));
                     obj_hit = false;
                 }
                 for (;;) {  // Engine::hit's loop over objects (path_integrator.rs:90-95)
@@ -239,7 +237,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     fresh = false;
                     if (obj >= sc.n_objects) {
                         if (ANY) io.emit_any(ray, false, vis);
-                        else io.emit_closest(ray, best_meta != RT_MISS, best_t, best_n, best_meta, best_prim, vis);
+                        else io.emit_closest(ray, got, vis);
                         ray = RAY_NONE;
                         break;
                     }
@@ -300,9 +298,8 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                             nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
                         }
                         best_t = t;
-                        best_n = nrm;
-                        best_meta = obj | (ff << 31);
-                        best_prim = 0;
+                        got = true;
+                        io.hit(ray, t, nrm, obj | (ff << 31), 0u);
                     }
                 }
             }

@@ -82,14 +82,26 @@ struct TraceIO {  // caller-provided SoA ray batch and hit arrays (rt_rays / rt_
         *o = v3(rays.ox[i], rays.oy[i], rays.oz[i]);
         *d = v3(rays.dx[i], rays.dy[i], rays.dz[i]);
     }
-    RT_DEV void emit_closest(uint32_t i, bool got, float t, V3 n, uint32_t meta, uint32_t prim, const Visits& vis) const {
-        out.t[i] = got ? t : __builtin_inff();
-        if (out.prim) out.prim[i] = got ? prim : RT_MISS;
-        if (out.obj) out.obj[i] = got ? (meta & 0x7FFFFFFFu) : RT_MISS;
-        if (out.nx) out.nx[i] = got ? n.x : 0.0f;
-        if (out.ny) out.ny[i] = got ? n.y : 0.0f;
-        if (out.nz) out.nz[i] = got ? n.z : 0.0f;
-        if (out.front_face) out.front_face[i] = got ? (uint8_t)(meta >> 31) : (uint8_t)0;
+    // a closer hit than any before it on this ray (Engine::hit's `closest = Some(..)`, :92-94)
+    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
+        out.t[i] = t;
+        if (out.prim) out.prim[i] = prim;
+        if (out.obj) out.obj[i] = meta & 0x7FFFFFFFu;
+        if (out.nx) out.nx[i] = n.x;
+        if (out.ny) out.ny[i] = n.y;
+        if (out.nz) out.nz[i] = n.z;
+        if (out.front_face) out.front_face[i] = (uint8_t)(meta >> 31);
+    }
+    RT_DEV void emit_closest(uint32_t i, bool got, const Visits& vis) const {
+        if (!got) {
+            out.t[i] = __builtin_inff();
+            if (out.prim) out.prim[i] = RT_MISS;
+            if (out.obj) out.obj[i] = RT_MISS;
+            if (out.nx) out.nx[i] = 0.0f;
+            if (out.ny) out.ny[i] = 0.0f;
+            if (out.nz) out.nz[i] = 0.0f;
+            if (out.front_face) out.front_face[i] = (uint8_t)0;
+        }
         if (out.n_int) out.n_int[i] = vis.n_int;
         if (out.n_tri) out.n_tri[i] = vis.n_tri;
     }
@@ -101,7 +113,7 @@ struct TraceIO {  // caller-provided SoA ray batch and hit arrays (rt_rays / rt_
 };
 
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceIO io, uint32_t n, float t_min, float t_max,
+__global__ RT_TRACE_ATTR void k_trace(DScene sc, TraceIO io, uint32_t n, float t_min, float t_max,
                                                     uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                     uint32_t overflow_stride) {
     constexpr int STACK = ANY ? RT_STACK_ANY : RT_STACK_LDS;

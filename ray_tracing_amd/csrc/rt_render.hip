@@ -47,7 +47,9 @@ struct PathArrays {      // SoA over slots
     uint32_t* shadow_q;
     uint32_t* qflags;    // per queue position: QF_* of the path there
     uint32_t* block_cnt; // [2][blocks]: alive, shadow totals per shade block
-    uint32_t* block_off; // [2][blocks]: exclusive scan
+    uint32_t* block_off; // [2][blocks]: exclusive scan inside the block's scan group
+    uint32_t* group_tot; // [2][groups]: totals of each group of SCAN_GROUP blocks
+    uint32_t* group_off; // [2][groups]: exclusive scan of the group totals
     uint32_t* totals;    // [0] next live count, [1] shadow count
     uint32_t* work;      // extend work counters [0, WORK_U32), shadow work counters [WORK_U32, 2*WORK_U32) (zeroed per iteration)
     unsigned long long* visit; // [0] n_int extend, [1] n_tri extend, [2] n_int shadow, [3] n_tri shadow
@@ -103,14 +105,14 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
     }
-    RT_DEV void emit_closest(uint32_t i, bool got, float t, V3 n, uint32_t meta, uint32_t prim, const Visits& vis) {
+    // a closer hit than any before it on this ray (Engine::hit's `closest = Some(..)`, :92-94)
+    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
         const uint32_t slot = queue[i];
-        if (got) {
-            pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
-            pa.hit_b[slot] = make_uint2(meta, prim);
-        } else {
-            pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
-        }
+        pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
+        pa.hit_b[slot] = make_uint2(meta, prim);
+    }
+    RT_DEV void emit_closest(uint32_t i, bool got, const Visits& vis) {
+        if (!got) pa.hit_b[queue[i]] = make_uint2(RT_MISS, RT_MISS);
         n_int += vis.n_int;
         n_tri += vis.n_tri;
     }
@@ -118,7 +120,7 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
 };
 
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n,
+__global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n,
                                                      uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                      uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
@@ -130,7 +132,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene sc, PathArrays pa, c
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     ExtendIO io{pa, queue, 0ull, 0ull};
     trace_loop<false, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                     lds_stack + threadIdx.x, overflow + gtid, overflow_stride, lds_stage);
+                                                     lds_stack + threadIdx.x, overflow + gtid, overflow_stride,
+                                                     lds_stage);
     if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
 }
 
@@ -144,7 +147,8 @@ struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds it
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
     }
-    RT_DEV void emit_closest(uint32_t, bool, float, V3, uint32_t, uint32_t, const Visits&) {}
+    RT_DEV void hit(uint32_t, float, V3, uint32_t, uint32_t) const {}
+    RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
     RT_DEV void emit_any(uint32_t i, bool occluded, const Visits& vis) {
         if (!occluded) {
             const uint32_t slot = pa.shadow_q[i];
@@ -164,7 +168,7 @@ struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds it
 
 // path_integrator.rs:219: the shadow ray is tested over T_MIN..T_MAX, not up to the light.
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene sc, PathArrays pa, uint32_t n, uint32_t* work_counter,
+__global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, uint32_t n, uint32_t* work_counter,
                                                      TraceTune tune, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_ANY * RT_BLOCK];
 #if RT_COOP
@@ -175,7 +179,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene sc, PathArrays pa, u
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     ShadowIO io{pa, 0ull, 0ull};
     trace_loop<true, COUNT, RT_STACK_ANY, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                    lds_stack + threadIdx.x, overflow + gtid, overflow_stride, lds_stage);
+                                                    lds_stack + threadIdx.x, overflow + gtid, overflow_stride,
+                                                    lds_stage);
     if (COUNT) add_visits(&pa.visit[2], io.n_int, io.n_tri);
 }
 
@@ -338,52 +343,71 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
 }
 
 // ---------------------------------------------------------------- compact
-// Exclusive scan of the per-block totals (one workgroup of 16 waves; at most 65 536 blocks per
-// batch): per-thread serial sums, wave-level shuffle scan, then a scan of the 16 wave totals.
-__global__ __launch_bounds__(1024) void k_compact_scan(PathArrays pa, uint32_t n_blocks) {
-    __shared__ uint32_t wave_sum[2][16];
-    const uint32_t per = (n_blocks + 1023u) / 1024u;
-    const uint32_t begin = threadIdx.x * per, end = min(begin + per, n_blocks);
+// Exclusive scan of the per-block totals in two levels, both queues (alive, shadow) at once:
+//   k_compact_scan_groups: one workgroup per 1024 consecutive shade blocks -- coalesced read, wave
+//       shuffle scan, LDS scan of the 16 wave totals; writes offsets local to the group + the group total
+//   k_compact_scan_top:    one workgroup scans the group totals (<= 8192 groups: 2^31 slots / 256 / 1024)
+// The scatter adds group offset + local offset.  (The first version scanned everything in ONE
+// workgroup with a serial strip per thread: 2.6 ms for the 518 400 blocks of a 64-spp 1080p batch.)
+constexpr uint32_t SCAN_GROUP = 1024;
+
+RT_DEV uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wave_sum /*[16]*/, uint32_t* total) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t own[2], incl[2];
-    for (int q = 0; q < 2; ++q) {
-        uint32_t s = 0;
-        for (uint32_t b = begin; b < end; ++b) s += pa.block_cnt[q * n_blocks + b];
-        own[q] = s;
-        uint32_t x = s;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t y = __shfl_up(x, off);
-            if (lane >= (uint32_t)off) x += y;
-        }
-        incl[q] = x;
-        if (lane == 63) wave_sum[q][wave] = x;
+    uint32_t x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off);
+        if (lane >= (uint32_t)off) x += y;
     }
+    if (lane == 63) wave_sum[wave] = x;
     __syncthreads();
     if (wave == 0) {
-        for (int q = 0; q < 2; ++q) {
-            uint32_t w = lane < 16 ? wave_sum[q][lane] : 0u;
-            uint32_t x = w;
-            for (int off = 1; off < 16; off <<= 1) {
-                uint32_t y = __shfl_up(x, off);
-                if (lane >= (uint32_t)off) x += y;
-            }
-            if (lane < 16) wave_sum[q][lane] = x - w;  // exclusive
-            if (lane == 15) pa.totals[q] = x;
+        uint32_t w = lane < 16 ? wave_sum[lane] : 0u;
+        uint32_t t = w;
+        for (int off = 1; off < 16; off <<= 1) {
+            uint32_t y = __shfl_up(t, off);
+            if (lane >= (uint32_t)off) t += y;
         }
+        if (lane < 16) wave_sum[lane] = t - w;  // exclusive over waves
+        if (lane == 15) *total = t;
     }
     __syncthreads();
+    return x - v + wave_sum[wave];
+}
+
+__global__ __launch_bounds__(1024) void k_compact_scan_groups(PathArrays pa, uint32_t n_blocks, uint32_t n_groups) {
+    __shared__ uint32_t wave_sum[2][16];
+    __shared__ uint32_t total[2];
+    const uint32_t b = blockIdx.x * SCAN_GROUP + threadIdx.x;
     for (int q = 0; q < 2; ++q) {
-        uint32_t run = incl[q] - own[q] + wave_sum[q][wave];
-        for (uint32_t b = begin; b < end; ++b) {
-            pa.block_off[q * n_blocks + b] = run;
-            run += pa.block_cnt[q * n_blocks + b];
+        const uint32_t v = b < n_blocks ? pa.block_cnt[q * n_blocks + b] : 0u;
+        const uint32_t e = block_excl_scan_1024(v, wave_sum[q], &total[q]);
+        if (b < n_blocks) pa.block_off[q * n_blocks + b] = e;
+    }
+    if (threadIdx.x < 2) pa.group_tot[threadIdx.x * n_groups + blockIdx.x] = total[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void k_compact_scan_top(PathArrays pa, uint32_t n_groups) {
+    __shared__ uint32_t wave_sum[2][16];
+    __shared__ uint32_t total[2];
+    const uint32_t per = (n_groups + 1023u) / 1024u;  // <= 8
+    const uint32_t begin = threadIdx.x * per, end = min(begin + per, n_groups);
+    for (int q = 0; q < 2; ++q) {
+        uint32_t s = 0;
+        for (uint32_t g = begin; g < end; ++g) s += pa.group_tot[q * n_groups + g];
+        uint32_t run = block_excl_scan_1024(s, wave_sum[q], &total[q]);
+        for (uint32_t g = begin; g < end; ++g) {
+            const uint32_t c = pa.group_tot[q * n_groups + g];
+            pa.group_off[q * n_groups + g] = run;
+            run += c;
         }
     }
+    if (threadIdx.x < 2) pa.totals[threadIdx.x] = total[threadIdx.x];
 }
 
 // Stable scatter: position = block offset + waves before + rank inside the wave ballot.
 __global__ __launch_bounds__(SHADE_BLOCK) void k_compact_scatter(PathArrays pa, const uint32_t* queue,
-                                                                 uint32_t* next_queue, uint32_t n, uint32_t n_blocks) {
+                                                                 uint32_t* next_queue, uint32_t n, uint32_t n_blocks,
+                                                                 uint32_t n_groups) {
     __shared__ uint32_t wave_cnt[2][SHADE_BLOCK / 64];
     uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
     uint32_t flags = i < n ? pa.qflags[i] : 0u;
@@ -398,12 +422,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_compact_scatter(PathArrays pa, 
     __syncthreads();
     unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     if (flags & QF_ALIVE) {
-        uint32_t pos = pa.block_off[blockIdx.x];
+        uint32_t pos = pa.group_off[blockIdx.x / SCAN_GROUP] + pa.block_off[blockIdx.x];
         for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[0][w];
         next_queue[pos + (uint32_t)__popcll(alive & below)] = slot;
     }
     if (flags & QF_SHADOW) {
-        uint32_t pos = pa.block_off[n_blocks + blockIdx.x];
+        uint32_t pos = pa.group_off[n_groups + blockIdx.x / SCAN_GROUP] + pa.block_off[n_blocks + blockIdx.x];
         for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[1][w];
         pa.shadow_q[pos + (uint32_t)__popcll(shadow & below)] = slot;
     }
@@ -507,7 +531,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
            o_meta = carve(P * 16), o_hit_a = carve(P * 16), o_hit_b = carve(P * 8), o_sh_o = carve(P * 16),
            o_sh_d = carve(P * 16), o_sh_c = carve(P * 16), o_q0 = carve(P * 4), o_q1 = carve(P * 4),
            o_sq = carve(P * 4), o_qf = carve(P * 4), o_bc = carve((size_t)max_blocks * 8),
-           o_bo = carve((size_t)max_blocks * 8), o_tot = carve(256), o_vis = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
+           o_bo = carve((size_t)max_blocks * 8), o_gt = carve(((size_t)max_blocks / 1024 + 1) * 8),
+           o_go = carve(((size_t)max_blocks / 1024 + 1) * 8), o_tot = carve(256), o_vis = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
     int rc = ctx->path_state.ensure(off);
     if (rc != RT_OK) return rc;
     char* base = (char*)ctx->path_state.p;
@@ -528,6 +553,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     pa.qflags = (uint32_t*)(base + o_qf);
     pa.block_cnt = (uint32_t*)(base + o_bc);
     pa.block_off = (uint32_t*)(base + o_bo);
+    pa.group_tot = (uint32_t*)(base + o_gt);
+    pa.group_off = (uint32_t*)(base + o_go);
     pa.totals = (uint32_t*)(base + o_tot);
     pa.work = (uint32_t*)(base + o_work);
     pa.visit = (unsigned long long*)(base + o_vis);
@@ -629,9 +656,11 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             if ((rc = t_end(2)) != RT_OK) return rc;
 
             if ((rc = t_begin(4)) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, stream, pa, n_blocks);
+            const uint32_t n_groups = (n_blocks + SCAN_GROUP - 1) / SCAN_GROUP;
+            hipLaunchKernelGGL(k_compact_scan_groups, dim3(n_groups), dim3(1024), 0, stream, pa, n_blocks, n_groups);
+            hipLaunchKernelGGL(k_compact_scan_top, dim3(1), dim3(1024), 0, stream, pa, n_groups);
             hipLaunchKernelGGL(k_compact_scatter, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, pa, pa.queue[cur],
-                               pa.queue[cur ^ 1], n, n_blocks);
+                               pa.queue[cur ^ 1], n, n_blocks, n_groups);
             if ((rc = t_end(4)) != RT_OK) return rc;
 
             uint32_t totals[2];
@@ -692,6 +721,13 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
 }
 
 #if RT_TRACE_STATS
+extern "C" int rt_debug_occupancy(int* out4) {  // resident workgroups per CU: extend, shadow, extend<count>, shade
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_extend<false>, RT_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_shadow<false>, RT_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend<true>, RT_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_shade, SHADE_BLOCK, 0) != hipSuccess) return -2;
+    return 0;
+}
 extern "C" int rt_debug_trace_stats(unsigned long long* out32, int reset) {
     if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(rtd::g_trace_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return -2;
     if (reset) {
