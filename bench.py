@@ -148,29 +148,35 @@ def main():
                                  flags=rt.api.RENDER_COUNT_VISITS, out=acc.data_ptr())
         last = {}
 
-        def step(record):
+        ext_ms, ext_launches = [], []
+
+        def step(record, all_stages=False):
             _, st = ctx.render(width, height, args.spp, args.depth, args.seed, spp_first,
-                               flags=rt.api.RENDER_TIME_STAGES if record else 0, out=acc.data_ptr())
+                               flags=rt.api.RENDER_TIME_STAGES if all_stages else 0, out=acc.data_ptr())
             if world > 1:
                 dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
             last["st"] = st
+            if record:  # k_extend is timed by HIP events on the library's stream in every render call
+                ext_ms.append(st.ms_extend)
+                ext_launches.append(st.launches_extend)
 
         for _ in range(args.warmup):
             step(False)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(False)
+            step(True)
         barrier()
         elapsed = time.perf_counter() - t0
-        # one more (untimed) step with per-stage HIP events for the roofline figure
-        step(True)
+        # one more (untimed) step with HIP events around every stage, for the breakdown in `detail`
+        step(False, all_stages=True)
         st = last["st"]
         rays_per_step = st.rays_closest + st.rays_shadow
         alg_bytes_total = 48 * st_count.rays_closest + 64 * st_count.nodes_visited + 40 * st_count.tris_tested
-        launches = max(1, st.launches_extend)
-        result.update(kernel="k_extend", kernel_ms=st.ms_extend / launches, alg_bytes=alg_bytes_total / launches,
-                      launches=int(launches), ms_extend=st.ms_extend, ms_shadow=st.ms_shadow, ms_shade=st.ms_shade,
+        launches = max(1, int(np.mean(ext_launches)))
+        ms_extend_timed = float(np.mean(ext_ms))  # average over the K timed frames
+        result.update(kernel="k_extend", kernel_ms=ms_extend_timed / launches, alg_bytes=alg_bytes_total / launches,
+                      launches=int(launches), ms_extend=ms_extend_timed, ms_shadow=st.ms_shadow, ms_shade=st.ms_shade,
                       ms_generate=st.ms_generate, ms_compact=st.ms_compact, ms_device_total=st.ms_total,
                       n_int_mean=st_count.nodes_visited / max(1, st_count.rays_closest),
                       n_tri_mean=st_count.tris_tested / max(1, st_count.rays_closest),
@@ -191,6 +197,8 @@ def main():
         total_rays_per_step = float(rays_per_step)
 
     if rank == 0:
+        stream_copy = stream_copy_gbs(torch, dev)
+        traffic = committed_traffic(args, result["kernel"])
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays_per_step * args.steps / elapsed / 1e6
         achieved = result["alg_bytes"] / (result["kernel_ms"] * 1e-3) / 1e9
@@ -201,7 +209,8 @@ def main():
             "config": {"workload": workload, "seed": args.seed, "parallelism": f"sample-sharded x{world}" if world > 1 else "1 GPU",
                        "ms_per_frame": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "stream_copy_GBs": round(stream_copy, 1),
                          "kernel": result["kernel"], "kernel_ms": round(result["kernel_ms"], 4),
                          "alg_bytes_per_launch": int(result["alg_bytes"]),
                          "n_int_per_ray": round(result["n_int_mean"], 3), "n_tri_per_ray": round(result["n_tri_mean"], 3)},
@@ -213,6 +222,43 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def stream_copy_gbs(torch, dev):
+    """Measured device-to-device copy rate (read + write bytes) on this GPU: the practical HBM ceiling
+    SURVEY.md 8(d) asks to report beside the 8 TB/s spec peak."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def committed_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes committed under profiles/
+    (scripts/pmc_traffic.sh; counters cannot be read from inside this process).  None unless a
+    committed measurement exists for exactly this workload."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "final", "pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        w = d.get("workload", {})
+        if (w.get("name") == args.workload and w.get("levels") == args.levels and w.get("width") == args.width
+                and w.get("spp") == args.spp and w.get("depth") == args.depth and kernel in d.get("kernels", {})):
+            k = d["kernels"][kernel]
+            return {"bytes_per_launch": k["hbm_bytes_per_launch"], "fetch_bytes": k["fetch_bytes"],
+                    "write_bytes": k["write_bytes"], "launches": k["launches"], "source": os.path.relpath(f, ROOT),
+                    "note": d.get("note", "")}
+    return None
 
 
 def cpu_baseline(args, desc, scene, width, height):
@@ -239,13 +285,24 @@ def cpu_baseline(args, desc, scene, width, height):
         rays = len(o) + len(p)
         return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
                 "sample": f"every 4th image row of the same ray batch ({rays} rays, {dt:.1f} s)"}
-    threads = args.cpu_threads
-    rows = (height // 2, height // 2 + 8)
-    spp = min(args.spp, 8)
-    _, st = orc.render(width, height, spp, args.depth, args.seed, 0, rows=rows, threads=threads)
-    rays = st.rays_closest + st.rays_shadow
-    return {"value": round(rays / st.seconds / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"rows {rows[0]}..{rows[1] - 1} of the same frame at {spp} spp ({rays} rays, {st.seconds:.1f} s)"}
+    # bounded sample: 7 bands of 8 image rows spread over the frame, at the full spp (about 7 M camera
+    # paths, 10-30 s on one core); the same sample again on all host cores
+    bands = [(int(height * (k + 0.5) / 7) - 4, int(height * (k + 0.5) / 7) + 4) for k in range(7)]
+
+    pixels = np.concatenate([np.arange(r0 * width, r1 * width, dtype=np.uint32) for r0, r1 in bands])
+
+    def run(threads):  # pixels are dealt to the workers one at a time
+        _, st = orc.render_pixels(width, height, pixels, args.spp, args.depth, args.seed, 0, threads=threads)
+        return st.rays_closest + st.rays_shadow, st.seconds
+
+    rays, secs = run(1)
+    ncores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    rays_all, secs_all = run(ncores)
+    return {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"56 image rows (7 bands of 8) of the same frame at {args.spp} spp ({rays} rays, {secs:.1f} s); "
+                      "1 thread = the reference's own execution model",
+            "all_cores": {"value": round(rays_all / secs_all / 1e6, 4), "unit": "Mrays/s", "cores": ncores,
+                          "seconds": round(secs_all, 1)}}
 
 
 if __name__ == "__main__":

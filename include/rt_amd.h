@@ -285,7 +285,7 @@ typedef struct rt_stats {
 } rt_stats;
 
 #define RT_RENDER_COUNT_VISITS 1u /* fill nodes_visited / tris_tested (slower kernel variant) */
-#define RT_RENDER_TIME_STAGES 2u  /* fill the per-stage ms_* fields (adds event records) */
+#define RT_RENDER_TIME_STAGES 2u  /* fill every per-stage ms_* field (adds event records); ms_extend is always filled */
 
 /* Engine::render (path_integrator.rs:278-318) minus the PPM text: for every pixel (i, j) adds
    ray_colour (:138-276) of samples [spp_first, spp_first+spp_count) IN SAMPLE ORDER and stores the

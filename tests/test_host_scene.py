@@ -38,6 +38,32 @@ def test_bvh_builder_matches_oracle_builder(levels):
     assert f.node_count <= 2 * f.tri_count - 1  # bvh.rs:62-66
 
 
+@pytest.mark.parametrize("threads", ["2", "5"])
+def test_parallel_bvh_build_is_node_for_node_the_serial_one(threads, monkeypatch):
+    """262 144 triangles take the parallel path (upper tree split by all threads,
+    subtrees <= 16 384 primitives as tasks, depth-first renumbering); nodes, boxes and the `indices`
+    permutation must equal the oracle's serial restatement of bvh.rs:60-241 bit for bit."""
+    monkeypatch.setenv("RT_BUILD_THREADS", threads)
+    desc = scenes.tetrahedron_scene(levels=8)
+    f = _same_bvh(rt.Scene(desc), ob.OracleScene(desc))
+    assert f.tri_count == 4 ** 9
+
+
+def test_parallel_bvh_build_on_soup_with_unsplittable_big_nodes(monkeypatch):
+    """40 000 random triangles of which 36 000 are copies of one: an upper-tree node that cannot be split."""
+    monkeypatch.setenv("RT_BUILD_THREADS", "4")
+    rng = np.random.default_rng(11)
+    v = rng.uniform(-1, 1, (3000, 3)).astype(np.float32)
+    t = rng.integers(0, 3000, (40000, 3)).astype(np.uint32)
+    t[2000:38000] = t[2000]
+    mesh = rt.Mesh.from_arrays(v, t)
+    desc = rt.SceneDescription()
+    desc.add_mesh(mesh, desc.diffuse((1, 1, 1)))
+    desc.point_light((0, 0, 5), (1, 1, 1))
+    desc.set_camera((0, -4, 0), (0, 1, 0), scenes.ASPECT_RATIO)
+    _same_bvh(rt.Scene(desc), ob.OracleScene(desc))
+
+
 def test_bvh_builder_on_irregular_soup():
     """Random triangle soup with duplicated and degenerate triangles (empty bins, failed partitions)."""
     rng = np.random.default_rng(5)
