@@ -172,12 +172,16 @@ def main():
         step(False, all_stages=True)
         st = last["st"]
         rays_per_step = st.rays_closest + st.rays_shadow
-        alg_bytes_total = 48 * st_count.rays_closest + 64 * st_count.nodes_visited + 40 * st_count.tris_tested
+        # algorithmic bytes of the rays k_extend traced (the tail kernel's share, if any, is not its work)
+        alg_bytes_total = (48 * (st_count.rays_closest - st_count.rays_closest_tail)
+                           + 64 * (st_count.nodes_visited - st_count.nodes_visited_tail)
+                           + 40 * (st_count.tris_tested - st_count.tris_tested_tail))
         launches = max(1, int(np.mean(ext_launches)))
         ms_extend_timed = float(np.mean(ext_ms))  # average over the K timed frames
         result.update(kernel="k_extend", kernel_ms=ms_extend_timed / launches, alg_bytes=alg_bytes_total / launches,
                       launches=int(launches), ms_extend=ms_extend_timed, ms_shadow=st.ms_shadow, ms_shade=st.ms_shade,
-                      ms_generate=st.ms_generate, ms_compact=st.ms_compact, ms_device_total=st.ms_total,
+                      ms_generate=st.ms_generate, ms_compact=st.ms_compact, ms_tail=st.ms_tail,
+                      paths_tail=int(st.paths_tail), ms_device_total=st.ms_total,
                       n_int_mean=st_count.nodes_visited / max(1, st_count.rays_closest),
                       n_tri_mean=st_count.tris_tested / max(1, st_count.rays_closest),
                       rays_closest=int(st.rays_closest), rays_shadow=int(st.rays_shadow),

@@ -282,9 +282,18 @@ typedef struct rt_stats {
     float ms_generate, ms_extend, ms_shade, ms_shadow, ms_compact;
     uint64_t launches_extend; /* number of extend launches (for per-launch averages) */
     uint64_t launches_shadow;
+    /* Share of the totals above that the tail kernel handled: once fewer than a threshold of paths
+       are alive, ONE launch carries each of them through all its remaining bounces. */
+    uint64_t paths_tail;
+    uint64_t rays_closest_tail, rays_shadow_tail;
+    uint64_t nodes_visited_tail, tris_tested_tail; /* closest-hit rays of the tail kernel */
+    uint64_t launches_tail;
+    float ms_tail;            /* always filled, like ms_extend */
+    uint32_t reserved;
 } rt_stats;
 
 #define RT_RENDER_COUNT_VISITS 1u /* fill nodes_visited / tris_tested (slower kernel variant) */
+#define RT_RENDER_NO_TAIL 4u      /* keep one launch per stage and bounce to the end (no tail kernel) */
 #define RT_RENDER_TIME_STAGES 2u  /* fill every per-stage ms_* field (adds event records); ms_extend is always filled */
 
 /* Engine::render (path_integrator.rs:278-318) minus the PPM text: for every pixel (i, j) adds

@@ -19,7 +19,7 @@ MAT_DIFFUSE, MAT_DIELECTRIC, MAT_CONDUCTOR = range(3)
 LIGHT_POINT, LIGHT_SPOT, LIGHT_AREA = range(3)
 MEDIUM_HOMOGENEOUS, MEDIUM_CHECKERED = range(2)
 MEDIUM_NONE, MEDIUM_AUTO = -1, -2
-RENDER_COUNT_VISITS, RENDER_TIME_STAGES = 1, 2
+RENDER_COUNT_VISITS, RENDER_TIME_STAGES, RENDER_NO_TAIL = 1, 2, 4
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -108,7 +108,10 @@ class Stats(C.Structure):
                 ("tris_tested_shadow", C.c_uint64), ("iterations", C.c_uint32),
                 ("batches", C.c_uint32), ("ms_total", C.c_float), ("ms_generate", C.c_float),
                 ("ms_extend", C.c_float), ("ms_shade", C.c_float), ("ms_shadow", C.c_float),
-                ("ms_compact", C.c_float), ("launches_extend", C.c_uint64), ("launches_shadow", C.c_uint64)]
+                ("ms_compact", C.c_float), ("launches_extend", C.c_uint64), ("launches_shadow", C.c_uint64),
+                ("paths_tail", C.c_uint64), ("rays_closest_tail", C.c_uint64), ("rays_shadow_tail", C.c_uint64),
+                ("nodes_visited_tail", C.c_uint64), ("tris_tested_tail", C.c_uint64), ("launches_tail", C.c_uint64),
+                ("ms_tail", C.c_float), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

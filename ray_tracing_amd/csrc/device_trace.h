@@ -1,10 +1,10 @@
 // Persistent-wave ray traversal: the hot loop behind rt_trace_closest / rt_trace_any / k_extend /
-// k_shadow.
+// k_shadow / k_tail.
 //
 // Why this shape (PMC profile of the first version, profiles/r01/pmc_trace_v0): with one static
 // strip of rays per lane the grid averaged 1.2 resident waves per SIMD (rays over background
 // finish at once, waves over the mesh run long) and a wave stalled on its slowest ray.  Here
-//   * a launch is a fixed number of waves that PULL rays from a global counter, so the chip stays
+//   * a launch is a fixed number of waves that PULL rays from work counters, so the chip stays
 //     full until the queue is empty;
 //   * each lane is a small state machine (advance-object / internal node / leaf) and an idle lane
 //     is refilled with a new ray as soon as >= refill_min lanes of its wave are idle, so one long
@@ -12,9 +12,13 @@
 //   * per ray the arithmetic and the visiting order are still exactly those of
 //     Engine::hit -> Object::hit -> traverse_bvh (path_integrator.rs:88-104, object.rs:32-87,
 //     bvh.rs:243-300): the schedule changes, the result (and the visit counters) do not.
+//
+// Tried and dropped (profiles/r01/tuning.md): one fetch shape serving node and leaf lanes in the same
+// iteration (every step then pays box AND triangle arithmetic: -14 %), and a quad-cooperative 64-byte
+// fetch transposed through LDS (3x the gather rate in scripts/microbench/gather64.hip, but its cost
+// is per iteration rather than per active lane: +-5 % here).
 #pragma once
 #include "device_scene.h"
-
 
 namespace rtd {
 
@@ -40,6 +44,11 @@ struct TraceTune {
 
 constexpr uint32_t RAY_NONE = 0xFFFFFFFFu;
 constexpr uint32_t REF_ADVANCE = 0xFFFFFFFFu;  // "current object finished": never a valid leaf ref
+constexpr uint32_t REF_DONE = 0xFFFFFFFEu;     // TRACE_PATH: ray finished, waiting for its continuation
+
+// What a lane's ray is: the kind fixed per kernel, or (TRACE_PATH) chosen per ray by the IO policy,
+// which then also supplies the NEXT ray of the same path when one finishes (k_tail).
+enum TraceMode { TRACE_CLOSEST = 0, TRACE_ANY = 1, TRACE_PATH = 2 };
 
 // 64-byte child pair / 48-byte triangle fetches with a 32-bit byte offset from a uniform base
 // (global_load_dwordx4 v, v_off, s[base]); rt_upload_scene bounds both arrays to < 4 GiB.
@@ -47,53 +56,19 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
     return *reinterpret_cast<const float4*>(static_cast<const char*>(base) + byte_off);
 }
 
-#ifndef RT_COOP
-#define RT_COOP 0
-#endif
-// Quad-cooperative record fetch (RT_COOP=1; compiled out by default -- see the end of this comment).
-// Measured on MI355X (scripts/microbench/gather64.hip): a wave in
-// which every lane reads its own 64-byte record with 4 x global_load_dwordx4 is limited by the
-// vector L1's divergent-access rate (one lane-line per clock: 99 G records/s chip-wide however small
-// the table), and the traversal ran at 76 G records/s -- against THAT ceiling, not HBM's.  When the 4
-// lanes of a quad read the 4 x 16 bytes of ONE record per instruction, each instruction touches 16
-// lines instead of 64 and the same gather runs at 230-300 G records/s.  The pieces are handed to
-// their owner through a per-lane 80-byte LDS slot (80, not 64: the slots of the 8 lanes served by
-// one LDS pass then fall on disjoint banks).
-// In the traversal loop the cooperative fetch costs the same whether 10 or 60 lanes need a record,
-// while the per-lane fetch is charged per active lane; at the ~45-50 % of lanes that advance per
-// iteration here the two came out within 5 % of each other (extend 54.8 ms cooperative vs 52.5 ms
-// per-lane, profiles/r01/tuning.md), so the simpler per-lane path is the default.
-typedef float f4v __attribute__((ext_vector_type(4)));  // native vector: assignable through an address-space pointer
-typedef __attribute__((address_space(3))) f4v lds_f4;
-RT_DEV f4v to_v(float4 a) { return f4v{a.x, a.y, a.z, a.w}; }
-RT_DEV float4 to_f4(f4v a) { return make_float4(a.x, a.y, a.z, a.w); }
-constexpr uint32_t STAGE_F4 = 5;  // float4 per lane slot
-template <int M>
-RT_DEV uint32_t quad_bcast(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, M * 0x55, 0xf, 0xf, true);
-}
-// every lane of the wave must call this (uniform control flow); off = this lane's record offset
-RT_DEV void coop_fetch64(const void* base, uint32_t off, lds_f4* stage_wave, uint32_t lane, float4* r0, float4* r1,
-                         float4* r2, float4* r3) {
-    const uint32_t j16 = (lane & 3u) << 4, q = lane & ~3u, j = lane & 3u;
-    const float4 p0 = ld16(base, quad_bcast<0>(off) + j16), p1 = ld16(base, quad_bcast<1>(off) + j16),
-                 p2 = ld16(base, quad_bcast<2>(off) + j16), p3 = ld16(base, quad_bcast<3>(off) + j16);
-    stage_wave[(q + 0u) * STAGE_F4 + j] = to_v(p0);
-    stage_wave[(q + 1u) * STAGE_F4 + j] = to_v(p1);
-    stage_wave[(q + 2u) * STAGE_F4 + j] = to_v(p2);
-    stage_wave[(q + 3u) * STAGE_F4 + j] = to_v(p3);
-    __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order; this only pins the code order
-    *r0 = to_f4(stage_wave[lane * STAGE_F4 + 0u]);
-    *r1 = to_f4(stage_wave[lane * STAGE_F4 + 1u]);
-    *r2 = to_f4(stage_wave[lane * STAGE_F4 + 2u]);
-    *r3 = to_f4(stage_wave[lane * STAGE_F4 + 3u]);
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <bool ANY, bool COUNT, int STACK_LDS, int BLOCK, class IO>
+// IO policy (one object per lane):
+//   load(i, &o, &d)                        world-space ray i of the launch
+//   hit(i, t, n, meta, prim)               closest-hit rays: a hit closer than any before it on ray i
+//   emit_closest(i, got, vis)              closest-hit ray i is finished
+//   emit_any(i, occluded, vis)             any-hit ray i is finished
+//   TRACE_PATH only:
+//   first_is_any(i)                        kind of the ray load() returned
+//   next(i, was_any, got, occluded, vis, &o, &d, &any) -> bool
+//                                          ray of item i finished; true = the lane continues with (o, d, any)
+template <int MODE, bool COUNT, int STACK_LDS, int BLOCK, class IO>
 RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
-                       float t_max_in,
-                       uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride, float4* lds_stage = nullptr) {
+                       float t_max_in, uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride) {
+    constexpr bool PATH = MODE == TRACE_PATH;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64u - lane));
     Stack<STACK_LDS, BLOCK> st;
@@ -101,10 +76,6 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     st.overflow = overflow;
     st.overflow_stride = overflow_stride;
     st.sp = 0;
-    // lds_stage: RT_BLOCK * STAGE_F4 float4 of LDS; this wave's 64 slots
-#if RT_COOP
-    lds_f4* const stage_wave = (lds_f4*)lds_stage + (threadIdx.x & ~63u) * STAGE_F4;
-#endif
 
     const uint32_t refill_min = tune.refill_min, chunk = tune.chunk;
     uint32_t ray = RAY_NONE;
@@ -121,10 +92,33 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     bool got = false;                                 // a hit has been recorded through io.hit()
     uint32_t hit_tri = 0;
     bool hit_ff = false, obj_hit = false, fresh = false;
+    bool lane_any = MODE == TRACE_ANY;                // TRACE_PATH: kind of this lane's current ray
+    bool done_occluded = false;                       // TRACE_PATH: outcome of a finished any-hit ray
     Visits vis = {0, 0};
 #if RT_TRACE_STATS
     unsigned long long s_stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+
+    // a ray is finished: hand it to the IO policy now, or (TRACE_PATH) park the lane for phase D
+    auto finish = [&](bool occluded) {
+        if constexpr (PATH) {
+            cur = REF_DONE;
+            done_occluded = occluded;
+        } else {
+            if constexpr (MODE == TRACE_ANY) io.emit_any(ray, occluded, vis);
+            else io.emit_closest(ray, got, vis);
+            ray = RAY_NONE;
+        }
+    };
+    auto begin_ray = [&]() {
+        best_t = t_max_in;
+        got = false;
+        cur = REF_ADVANCE;
+        obj_hit = false;
+        fresh = true;
+        st.sp = 0;
+        if (COUNT) vis = {0, 0};
+    };
 
     for (;;) {
         // ---------------------------------------------------------------- refill idle lanes
@@ -159,13 +153,8 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     if (idle && rank < take) {
                         ray = pool_next + rank;
                         io.load(ray, &wo, &wd);
-                        best_t = t_max_in;
-                        got = false;
-                        cur = REF_ADVANCE;
-                        obj_hit = false;
-                        fresh = true;
-                        st.sp = 0;
-                        if (COUNT) vis = {0, 0};
+                        if constexpr (PATH) lane_any = io.first_is_any(ray);
+                        begin_ray();
                     }
                     pool_next += take;
                 }
@@ -175,35 +164,25 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         // PMC of the run-every-phase version: 24 % VALU lane utilisation (a phase ran whenever a
         // single lane needed it).  Lanes now wait in their state until their phase is the best use
         // of the next issue slots; only that phase runs in this iteration.
+        const bool any = PATH ? lane_any : MODE == TRACE_ANY;
         const bool adv = ray != RAY_NONE && cur == REF_ADVANCE;
+        const bool isdone = PATH && ray != RAY_NONE && cur == REF_DONE;
         const bool isnode = ray != RAY_NONE && (cur & LEAF_BIT) == 0u;
-        const bool isleaf = ray != RAY_NONE && (cur & LEAF_BIT) != 0u && cur != REF_ADVANCE;
+        const bool isleaf = ray != RAY_NONE && (cur & LEAF_BIT) != 0u && cur < REF_DONE;
         const uint32_t n_adv = (uint32_t)__popcll(__ballot(adv)), n_node = (uint32_t)__popcll(__ballot(isnode)),
                        n_leaf = (uint32_t)__popcll(__ballot(isleaf));
-        if ((n_adv | n_node | n_leaf) == 0u) break;
-#if RT_COOP
-        // Cooperative mode: ONE 64-byte fetch per lane per iteration serves node lanes (child pair)
-        // and leaf lanes (triangle) alike -- its cost does not depend on how many lanes use it --
-        // so every lane inside a tree moves on each traversal iteration.  The triangle arithmetic
-        // (the expensive half) is deferred until enough leaf lanes have gathered; a waiting leaf
-        // lane simply receives its triangle again.
-        const bool run_trav = (n_node + n_leaf) * tune.w_node >= n_adv * tune.w_adv && (n_node + n_leaf) > 0u;
-        const bool run_adv = !run_trav;
-        const bool run_tri = run_trav && n_leaf * tune.w_leaf >= n_node;
-#else
+        const uint32_t n_done = PATH ? (uint32_t)__popcll(__ballot(isdone)) : 0u;
+        if ((n_adv | n_node | n_leaf | n_done) == 0u) break;
         const uint32_t s_adv = n_adv * tune.w_adv, s_node = n_node * tune.w_node, s_leaf = n_leaf * tune.w_leaf;
-        const bool run_node = s_node >= s_leaf && s_node >= s_adv;
-        const bool run_leaf = !run_node && s_leaf >= s_adv;
-        const bool run_adv = !run_node && !run_leaf;
-#endif
+        // TRACE_PATH: continuations go first once a fifth of the busy lanes wait for one (running every
+        // phase in every iteration instead was measured slower: 6.3 ms against 4.0 ms for 219 000 paths)
+        const bool run_done = PATH && n_done > 0u && 4u * n_done >= n_adv + n_node + n_leaf;
+        const bool run_node = !run_done && n_node > 0u && s_node >= s_leaf && s_node >= s_adv;
+        const bool run_leaf = !run_done && !run_node && n_leaf > 0u && s_leaf >= s_adv;
+        const bool run_adv = !run_done && !run_node && !run_leaf;
 #if RT_TRACE_STATS
         if (lane == 0) {
-#if RT_COOP
-            const uint32_t run = run_trav ? n_node + (run_tri ? n_leaf : 0u) : n_adv;
-            const bool run_node = run_trav, run_leaf = run_tri;
-#else
             const uint32_t run = run_node ? n_node : run_leaf ? n_leaf : n_adv;
-#endif
             RT_STAT(0, 1);                         // iterations
             RT_STAT(1, run);                       // lanes that advance
             RT_STAT(2, n_adv + n_node + n_leaf - run);  // lanes waiting for another phase
@@ -213,6 +192,20 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             RT_STAT(7, run_adv ? 1 : 0);
         }
 #endif
+
+        // ---------------------------------------------------------------- D: continuation (TRACE_PATH)
+        if constexpr (PATH) {
+            if (run_done && isdone) {
+                bool next_any = false;
+                if (io.next(ray, lane_any, got, done_occluded, vis, &wo, &wd, &next_any)) {
+                    lane_any = next_any;
+                    begin_ray();
+                } else {
+                    ray = RAY_NONE;
+                    cur = REF_ADVANCE;
+                }
+            }
+        }
 
         // ---------------------------------------------------------------- A: next object
         if (run_adv) {
@@ -236,9 +229,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     obj = fresh ? 0u : obj + 1u;
                     fresh = false;
                     if (obj >= sc.n_objects) {
-                        if (ANY) io.emit_any(ray, false, vis);
-                        else io.emit_closest(ray, got, vis);
-                        ray = RAY_NONE;
+                        finish(false);
                         break;
                     }
                     const DObject& ob = sc.objects[obj];
@@ -250,7 +241,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                         nr = norm_recip(d);
                         d = d * nr;
                     }
-                    const float t_lim = ANY ? t_max_in : best_t;
+                    const float t_lim = any ? t_max_in : best_t;
                     if (ob.kind == RT_SURF_MESH) {
                         inv = v3(recip(d.x), recip(d.y), recip(d.z));
                         // Skip a mesh whose ROOT box the ray misses.  The reference never tests the
@@ -288,9 +279,8 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                         ff = det > 0.0f;
                     }
                     if (h) {
-                        if (ANY) {
-                            io.emit_any(ray, true, vis);
-                            ray = RAY_NONE;
+                        if (any) {
+                            finish(true);
                             break;
                         }
                         if (ob.has_transform) {
@@ -305,59 +295,6 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             }
         }
 
-#if RT_COOP
-        // ---------------------------------------------------------------- B+C: traversal step
-        if (run_trav) {
-            const uint32_t k = cur & ~LEAF_BIT;
-            const uint32_t off = isnode ? cur << 6 : isleaf ? sc.tri_off + k * 48u : 0u;
-            float4 a0, a1, b0, b1;
-            coop_fetch64(sc.pairs, off, stage_wave, lane, &a0, &a1, &b0, &b1);
-            if (isnode) {
-                if (COUNT) vis.n_int += 1;
-                float lo1[3] = {a0.x, a0.y, a0.z}, hi1[3] = {a0.w, a1.x, a1.y};
-                float lo2[3] = {b0.x, b0.y, b0.z}, hi2[3] = {b0.w, b1.x, b1.y};
-                const uint32_t ref1 = __float_as_uint(a1.z), ref2 = __float_as_uint(b1.z);
-                float t1, t2;
-                const bool h1 = aabb_hit(lo1, hi1, o, inv, t_min, tmax, &t1);
-                const bool h2 = aabb_hit(lo2, hi2, o, inv, t_min, tmax, &t2);
-                if (h1 && h2) {  // bvh.rs:287-295: far pushed, near next; near = child1 unless t1 > t2
-                    const bool swap = t1 > t2;
-                    st.push(swap ? ref1 : ref2);
-                    cur = swap ? ref2 : ref1;
-                } else if (h1) {
-                    cur = ref1;
-                } else if (h2) {
-                    cur = ref2;
-                } else {
-                    cur = st.sp == 0 ? REF_ADVANCE : st.pop();
-                }
-            }
-            if (run_tri) {
-                if (isleaf) {  // one primitive of the leaf per step, in `indices` order (bvh.rs:256-266)
-                    if (COUNT) vis.n_tri += 1;
-                    float t, det;
-                    bool done = false;
-                    if (tri_hit(v3(a0.x, a0.y, a0.z), v3(a1.x, a1.y, a1.z), v3(b0.x, b0.y, b0.z), o, d, t_min, tmax, &t,
-                                &det)) {
-                        if (ANY) {
-                            io.emit_any(ray, true, vis);
-                            ray = RAY_NONE;
-                            done = true;
-                        } else {
-                            tmax = t;
-                            hit_tri = k;
-                            hit_ff = det > 0.0f;
-                            obj_hit = true;
-                        }
-                    }
-                    if (!done) {
-                        if (__float_as_uint(a1.w)) cur = st.sp == 0 ? REF_ADVANCE : st.pop();
-                        else cur = LEAF_BIT | (k + 1u);
-                    }
-                }
-            }
-        }
-#else
         // ---------------------------------------------------------------- B: internal node
         if (run_node) {
             if (isnode) {
@@ -397,9 +334,8 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     float t, det;
                     if (tri_hit(v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), o, d, t_min, tmax, &t,
                                 &det)) {
-                        if (ANY) {
-                            io.emit_any(ray, true, vis);
-                            ray = RAY_NONE;
+                        if (any) {
+                            finish(true);
                             done = true;
                             break;
                         }
@@ -414,11 +350,10 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                 if (!done) cur = st.sp == 0 ? REF_ADVANCE : st.pop();
             }
         }
-#endif
     }
 #if RT_TRACE_STATS
     if (lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_trace_stats[(ANY ? 8 : 0) + i], s_stat[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_trace_stats[(MODE == TRACE_ANY ? 8 : 0) + i], s_stat[i]);
 #endif
 }
 

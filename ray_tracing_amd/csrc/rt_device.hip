@@ -118,14 +118,10 @@ __global__ RT_TRACE_ATTR void k_trace(DScene sc, TraceIO io, uint32_t n, float t
                                                     uint32_t overflow_stride) {
     constexpr int STACK = ANY ? RT_STACK_ANY : RT_STACK_LDS;
     __shared__ uint32_t lds_stack[STACK * RT_BLOCK];
-#if RT_COOP
-    __shared__ float4 lds_stage[RT_BLOCK * rtd::STAGE_F4];
-#else
-    float4* const lds_stage = nullptr;
-#endif
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    trace_loop<ANY, COUNT, STACK, RT_BLOCK>(sc, io, n, work_counter, tune, t_min, t_max, lds_stack + threadIdx.x,
-                                            overflow + gtid, overflow_stride, lds_stage);
+    trace_loop<ANY ? TRACE_ANY : TRACE_CLOSEST, COUNT, STACK, RT_BLOCK>(sc, io, n, work_counter, tune, t_min, t_max,
+                                                                        lds_stack + threadIdx.x, overflow + gtid,
+                                                                        overflow_stride);
 }
 
 // ---------------------------------------------------------------- helpers

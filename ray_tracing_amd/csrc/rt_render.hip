@@ -52,6 +52,7 @@ struct PathArrays {      // SoA over slots
     uint32_t* group_off; // [2][groups]: exclusive scan of the group totals
     uint32_t* totals;    // [0] next live count, [1] shadow count
     uint32_t* work;      // extend work counters [0, WORK_U32), shadow work counters [WORK_U32, 2*WORK_U32) (zeroed per iteration)
+    unsigned long long* tail;   // k_tail totals (see k_tail)
     unsigned long long* visit; // [0] n_int extend, [1] n_tri extend, [2] n_int shadow, [3] n_tri shadow
 };
 
@@ -124,16 +125,10 @@ __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t*
                                                      uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                      uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-#if RT_COOP
-    __shared__ float4 lds_stage[RT_BLOCK * rtd::STAGE_F4];
-#else
-    float4* const lds_stage = nullptr;
-#endif
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     ExtendIO io{pa, queue, 0ull, 0ull};
-    trace_loop<false, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                     lds_stack + threadIdx.x, overflow + gtid, overflow_stride,
-                                                     lds_stage);
+    trace_loop<TRACE_CLOSEST, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+                                                             lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
 }
 
@@ -171,16 +166,10 @@ template <bool COUNT>
 __global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, uint32_t n, uint32_t* work_counter,
                                                      TraceTune tune, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_ANY * RT_BLOCK];
-#if RT_COOP
-    __shared__ float4 lds_stage[RT_BLOCK * rtd::STAGE_F4];
-#else
-    float4* const lds_stage = nullptr;
-#endif
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     ShadowIO io{pa, 0ull, 0ull};
-    trace_loop<true, COUNT, RT_STACK_ANY, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                    lds_stack + threadIdx.x, overflow + gtid, overflow_stride,
-                                                    lds_stage);
+    trace_loop<TRACE_ANY, COUNT, RT_STACK_ANY, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+                                                         lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     if (COUNT) add_visits(&pa.visit[2], io.n_int, io.n_tri);
 }
 
@@ -339,6 +328,114 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
         uint32_t s = 0;
         for (int w = 0; w < SHADE_BLOCK / 64; ++w) s += wave_cnt[threadIdx.x][w];
         pa.block_cnt[threadIdx.x * n_blocks + blockIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------- tail
+// A frame of a few thousand paths spends its time in launches and host round trips (5 launches and a
+// sync per bounce).  When no more than RT_TAIL_PATHS (default 32 768) paths are alive, k_tail runs each
+// of them to its end inside ONE persistent launch: a lane traces the path's ray, shades the vertex when
+// the ray finishes (the same shade_path), traces the shadow ray if one was produced, adds the pending
+// light term if it is unoccluded, and goes on with the next bounce.  Per path the order of operations
+// -- and of the float additions into its radiance -- is the wavefront's, so the image is bit-identical
+// (tests/test_render_gpu.py renders every scene both ways).
+// It is NOT a cure for the tail of a big frame: there every bounce is bounded by its longest ray
+// (hundreds of dependent fetches, ~0.35 ms) in either scheme, and with shading inside the traversal loop
+// each iteration costs more -- 219 000 paths took 4.0 ms here against 4.3 ms as five wavefront rounds
+// (profiles/r01/tuning.md), hence the low threshold.
+struct TailIO {
+    PathArrays pa;
+    const uint32_t* queue;
+    const DScene* sc;
+    const RenderParams* rp;
+    uint32_t n_closest, n_shadow, iters, max_iters;  // per lane
+    unsigned long long n_int, n_tri;                   // closest-hit visits (COUNT)
+    unsigned long long n_int_sh, n_tri_sh;             // shadow visits (COUNT)
+    bool alive_after;                                  // the path goes on after its pending shadow ray
+    RT_DEV void load(uint32_t i, V3* o, V3* d) {
+        const uint32_t slot = queue[i];
+        float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
+        *o = v3(o4.x, o4.y, o4.z);
+        *d = v3(d4.x, d4.y, d4.z);
+        n_closest += 1;
+        iters = 1;
+        if (iters > max_iters) max_iters = iters;
+    }
+    RT_DEV bool first_is_any(uint32_t) const { return false; }
+    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
+        const uint32_t slot = queue[i];
+        pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
+        pa.hit_b[slot] = make_uint2(meta, prim);
+    }
+    RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
+    RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
+    RT_DEV bool next_bounce(uint32_t slot, V3* o, V3* d, bool* any) {
+        float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
+        *o = v3(o4.x, o4.y, o4.z);
+        *d = v3(d4.x, d4.y, d4.z);
+        *any = false;
+        n_closest += 1;
+        iters += 1;
+        if (iters > max_iters) max_iters = iters;
+        return true;
+    }
+    RT_DEV bool next(uint32_t i, bool was_any, bool got, bool occluded, const Visits& vis, V3* o, V3* d, bool* any) {
+        const uint32_t slot = queue[i];
+        if (!was_any) {
+            n_int += vis.n_int;
+            n_tri += vis.n_tri;
+            if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
+            const uint32_t flags = shade_path(*sc, pa, *rp, slot);
+            alive_after = (flags & QF_ALIVE) != 0;
+            if (flags & QF_SHADOW) {
+                float4 o4 = pa.sh_o[slot], d4 = pa.sh_d[slot];
+                *o = v3(o4.x, o4.y, o4.z);
+                *d = v3(d4.x, d4.y, d4.z);
+                *any = true;
+                n_shadow += 1;
+                return true;
+            }
+        } else {
+            n_int_sh += vis.n_int;
+            n_tri_sh += vis.n_tri;
+            if (!occluded) {
+                float4 c = pa.sh_c[slot];
+                if (c.w != 0.0f) {  // p_light > 0 (path_integrator.rs:234)
+                    float4 r = pa.rad[slot];
+                    r.x += c.x;
+                    r.y += c.y;
+                    r.z += c.z;
+                    pa.rad[slot] = r;
+                }
+            }
+        }
+        return alive_after ? next_bounce(slot, o, d, any) : false;
+    }
+};
+
+RT_DEV unsigned long long wave_sum_u64(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// pa.tail[0..7]: closest rays, shadow rays, n_int, n_tri (closest), n_int, n_tri (shadow), max iterations, unused
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, RenderParams rp, const uint32_t* queue,
+                                                   uint32_t n, uint32_t* work_counter, TraceTune tune,
+                                                   uint32_t* overflow, uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    TailIO io{pa, queue, &sc, &rp, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false};
+    trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    unsigned long long v[6] = {io.n_closest, io.n_shadow, io.n_int, io.n_tri, io.n_int_sh, io.n_tri_sh};
+    uint32_t mx = io.max_iters;
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
+    for (int k = 0; k < 6; ++k) v[k] = wave_sum_u64(v[k]);
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 6; ++k)
+            if (v[k]) atomicAdd(&pa.tail[k], v[k]);
+        atomicMax(&pa.tail[6], (unsigned long long)mx);
     }
 }
 
@@ -532,7 +629,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
            o_sh_d = carve(P * 16), o_sh_c = carve(P * 16), o_q0 = carve(P * 4), o_q1 = carve(P * 4),
            o_sq = carve(P * 4), o_qf = carve(P * 4), o_bc = carve((size_t)max_blocks * 8),
            o_bo = carve((size_t)max_blocks * 8), o_gt = carve(((size_t)max_blocks / 1024 + 1) * 8),
-           o_go = carve(((size_t)max_blocks / 1024 + 1) * 8), o_tot = carve(256), o_vis = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
+           o_go = carve(((size_t)max_blocks / 1024 + 1) * 8), o_tot = carve(256), o_vis = carve(256), o_tail = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
     int rc = ctx->path_state.ensure(off);
     if (rc != RT_OK) return rc;
     char* base = (char*)ctx->path_state.p;
@@ -558,7 +655,9 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     pa.totals = (uint32_t*)(base + o_tot);
     pa.work = (uint32_t*)(base + o_work);
     pa.visit = (unsigned long long*)(base + o_vis);
+    pa.tail = (unsigned long long*)(base + o_tail);
     RT_HIP(hipMemsetAsync(pa.visit, 0, 256, stream));
+    RT_HIP(hipMemsetAsync(pa.tail, 0, 256, stream));
 
     // ---- output: device accumulator (the caller's buffer if it is device memory)
     float* d_sum = rgb_sum;
@@ -575,22 +674,29 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     uint32_t* overflow = (uint32_t*)ctx->overflow.p;
 
     const bool count = (flags & RT_RENDER_COUNT_VISITS) != 0;
+    const bool use_tail = (flags & RT_RENDER_NO_TAIL) == 0;
+    static const uint32_t tail_paths = [] {  // RT_TAIL_PATHS overrides the switch-over point (experiments)
+        const char* e = getenv("RT_TAIL_PATHS");
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : 32768u;
+    }();
     const bool timing = (flags & RT_RENDER_TIME_STAGES) != 0;
     // HIP events on the library's stream around every launch of a stage.  k_extend (index 1, the kernel
     // the roofline figure is about) is always timed -- two event records per iteration; the other
     // stages only with RT_RENDER_TIME_STAGES.
-    StageTimer tm[5];  // generate, extend, shade, shadow, compact
-    for (int k = 0; k < 5; ++k)
-        if (timing || k == 1) {
+    constexpr int N_STAGES = 6;
+    StageTimer tm[N_STAGES];  // generate, extend, shade, shadow, compact, tail
+    auto timed = [&](int k) { return timing || k == 1 || k == 5; };
+    for (int k = 0; k < N_STAGES; ++k)
+        if (timed(k)) {
             RT_HIP(hipEventCreate(&tm[k].a));
             RT_HIP(hipEventCreate(&tm[k].b));
         }
     auto t_begin = [&](int k) -> int {
-        if (timing || k == 1) RT_HIP(hipEventRecord(tm[k].a, stream));
+        if (timed(k)) RT_HIP(hipEventRecord(tm[k].a, stream));
         return RT_OK;
     };
     auto t_end = [&](int k) -> int {
-        if (timing || k == 1) {
+        if (timed(k)) {
             RT_HIP(hipEventRecord(tm[k].b, stream));
             tm[k].pending = true;
         }
@@ -642,6 +748,25 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
             const int tgrid = (int)std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
             RT_HIP(hipMemsetAsync(pa.work, 0, 2 * rtd::WORK_U32 * 4, stream));
+            if (use_tail && n <= tail_paths) {  // few paths left: one launch takes them to their end
+                RT_HIP(hipMemsetAsync(pa.tail + 6, 0, 8, stream));
+                if ((rc = t_begin(5)) != RT_OK) return rc;
+                if (count)
+                    hipLaunchKernelGGL(k_tail<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
+                                       pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
+                else
+                    hipLaunchKernelGGL(k_tail<false>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
+                                       pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
+                if ((rc = t_end(5)) != RT_OK) return rc;
+                unsigned long long tail_iters = 0;
+                RT_HIP(hipMemcpyAsync(&tail_iters, pa.tail + 6, 8, hipMemcpyDeviceToHost, stream));
+                RT_HIP(hipStreamSynchronize(stream));
+                if ((rc = t_collect()) != RT_OK) return rc;
+                st.paths_tail += n;
+                st.launches_tail += 1;
+                iter += (uint32_t)tail_iters;
+                break;
+            }
             if ((rc = t_begin(1)) != RT_OK) return rc;
             if (count)
                 hipLaunchKernelGGL(k_extend<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
@@ -699,23 +824,31 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     }
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev[1], stream));
-    unsigned long long visit[4] = {0, 0, 0, 0};
+    unsigned long long visit[4] = {0, 0, 0, 0}, tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (count) RT_HIP(hipMemcpyAsync(visit, pa.visit, sizeof visit, hipMemcpyDeviceToHost, stream));
+    if (st.launches_tail) RT_HIP(hipMemcpyAsync(tail, pa.tail, sizeof tail, hipMemcpyDeviceToHost, stream));
     if (host_out) RT_HIP(hipMemcpyAsync(rgb_sum, d_sum, sum_bytes, hipMemcpyDeviceToHost, stream));
     RT_HIP(hipStreamSynchronize(stream));
     if ((rc = t_collect()) != RT_OK) return rc;
     RT_HIP(hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[1]));
-    st.nodes_visited = visit[0];
-    st.tris_tested = visit[1];
-    st.nodes_visited_shadow = visit[2];
-    st.tris_tested_shadow = visit[3];
+    st.rays_closest_tail = tail[0];
+    st.rays_shadow_tail = tail[1];
+    st.nodes_visited_tail = tail[2];
+    st.tris_tested_tail = tail[3];
+    st.rays_closest += tail[0];
+    st.rays_shadow += tail[1];
+    st.nodes_visited = visit[0] + tail[2];
+    st.tris_tested = visit[1] + tail[3];
+    st.nodes_visited_shadow = visit[2] + tail[4];
+    st.tris_tested_shadow = visit[3] + tail[5];
+    st.ms_tail = tm[5].ms;
     st.ms_generate = tm[0].ms;
     st.ms_extend = tm[1].ms;
     st.ms_shade = tm[2].ms;
     st.ms_shadow = tm[3].ms;
     st.ms_compact = tm[4].ms;
-    for (int k = 0; k < 5; ++k)
-        if (timing || k == 1) {
+    for (int k = 0; k < N_STAGES; ++k)
+        if (timed(k)) {
             (void)hipEventDestroy(tm[k].a);
             (void)hipEventDestroy(tm[k].b);
         }

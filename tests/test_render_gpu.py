@@ -36,8 +36,19 @@ def _check(ctx, desc, w, h, spp, depth, seed=0, spp_first=0, max_paths=None):
     assert st.tris_tested + st.tris_tested_shadow == ost.tris_tested
     assert st.paths == w * h * spp
     # the non-counting kernels give the same image
-    img2, _ = ctx.render(w, h, spp, depth, seed, spp_first)
+    img2, st2 = ctx.render(w, h, spp, depth, seed, spp_first)
     assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32))
+    assert (st2.rays_closest, st2.rays_shadow) == (ost.rays_closest, ost.rays_shadow)
+    # frames this small go to the tail kernel at once (every path alive <= its threshold); the pure
+    # wavefront pipeline -- one launch per stage and bounce -- must give the same image and counters
+    assert st.launches_tail >= 1 and st.paths_tail > 0
+    for fl in (rt.api.RENDER_NO_TAIL | rt.api.RENDER_COUNT_VISITS, rt.api.RENDER_NO_TAIL):
+        img3, st3 = ctx.render(w, h, spp, depth, seed, spp_first, flags=fl)
+        assert st3.launches_tail == 0 and st3.rays_closest_tail == 0
+        assert np.array_equal(img3.view(np.uint32), ref.view(np.uint32))
+        assert (st3.rays_closest, st3.rays_shadow) == (ost.rays_closest, ost.rays_shadow)
+        assert st3.iterations == st.iterations
+    assert st3.launches_extend >= st3.iterations
     ctx.set_max_paths_in_flight(0)
     return img, st, ost
 
