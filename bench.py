@@ -202,7 +202,7 @@ def main():
 
     if rank == 0:
         stream_copy = stream_copy_gbs(torch, dev)
-        traffic = committed_traffic(args, result["kernel"])
+        traffic, traffic_detail = committed_traffic(args, result["kernel"])
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays_per_step * args.steps / elapsed / 1e6
         achieved = result["alg_bytes"] / (result["kernel_ms"] * 1e-3) / 1e9
@@ -214,6 +214,7 @@ def main():
                        "ms_per_frame": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC, committed profile)", "traffic_detail": traffic_detail,
                          "stream_copy_GBs": round(stream_copy, 1),
                          "kernel": result["kernel"], "kernel_ms": round(result["kernel_ms"], 4),
                          "alg_bytes_per_launch": int(result["alg_bytes"]),
@@ -259,10 +260,10 @@ def committed_traffic(args, kernel):
         if (w.get("name") == args.workload and w.get("levels") == args.levels and w.get("width") == args.width
                 and w.get("spp") == args.spp and w.get("depth") == args.depth and kernel in d.get("kernels", {})):
             k = d["kernels"][kernel]
-            return {"bytes_per_launch": k["hbm_bytes_per_launch"], "fetch_bytes": k["fetch_bytes"],
-                    "write_bytes": k["write_bytes"], "launches": k["launches"], "source": os.path.relpath(f, ROOT),
-                    "note": d.get("note", "")}
-    return None
+            return k["hbm_bytes_per_launch"], {"fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
+                                               "launches": k["launches"], "l2_hit_rate": k.get("l2_hit_rate"),
+                                               "source": os.path.relpath(f, ROOT), "note": d.get("note", "")}
+    return None, None
 
 
 def cpu_baseline(args, desc, scene, width, height):
