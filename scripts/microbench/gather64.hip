@@ -28,6 +28,20 @@ __global__ __launch_bounds__(256) void kA(const void* buf, uint32_t mask, int it
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// A2: the same chain, but only the second 32 bytes of each record are read (2 x dwordx4 per lane)
+__global__ __launch_bounds__(256) void kA2(const void* buf, uint32_t mask, int iters, uint32_t* out) {
+    const uint32_t gt = blockIdx.x * 256 + threadIdx.x;
+    uint32_t idx = gt * 2654435761u & mask, acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        uint32_t off = idx << 6;
+        float4 c = ld16(buf, off + 32), d = ld16(buf, off + 48);
+        uint32_t m = mix(c, d, c, d);
+        acc += m;
+        idx = (m + i + gt * 0x9E3779B9u) & mask;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(256) void kB(const void* buf, uint32_t mask, int iters, uint32_t* out) {
     __shared__ __attribute__((aligned(16))) char stage[256 * 80];
     const uint32_t tid = threadIdx.x, j = tid & 3u, q = tid & ~3u;
@@ -81,13 +95,14 @@ int main(int argc, char** argv) {
         for (auto& v : h) { s = s * 1664525u + 1013904223u; v = s >> 4; }
         CK(hipMemcpy(buf, h.data(), bytes, hipMemcpyHostToDevice));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        float ms[3];
-        for (int k = 0; k < 3; ++k) {
+        float ms[4];
+        for (int k = 0; k < 4; ++k) {
             if (k == 2 && lg != 10) { ms[2] = 0; continue; }
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipEventRecord(e0));
                 if (k == 0) hipLaunchKernelGGL(kA, dim3(grid), dim3(256), 0, 0, buf, (uint32_t)(recs - 1), iters, out);
                 if (k == 1) hipLaunchKernelGGL(kB, dim3(grid), dim3(256), 0, 0, buf, (uint32_t)(recs - 1), iters, out);
+                if (k == 3) hipLaunchKernelGGL(kA2, dim3(grid), dim3(256), 0, 0, buf, (uint32_t)(recs - 1), iters, out);
                 if (k == 2) hipLaunchKernelGGL(kC, dim3(grid), dim3(256), 0, 0, buf, (uint32_t)(recs - 1), iters, out);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[k], e0, e1));
             }
@@ -98,6 +113,7 @@ int main(int argc, char** argv) {
         printf("records 2^%d (%8.1f MiB): A per-lane %.3f ms (%.1f G rec/s, %.0f GB/s)  B quad-coop %.3f ms (%.1f G rec/s, %.0f GB/s)  %s", lg,
                bytes / 1048576.0, ms[0], gathers / ms[0] / 1e6, gathers * 64 / ms[0] / 1e6, ms[1], gathers / ms[1] / 1e6,
                gathers * 64 / ms[1] / 1e6, ha == hb ? "match" : "MISMATCH");
+        printf("  A2 per-lane 32B %.3f ms (%.1f G rec/s)", ms[3], gathers / ms[3] / 1e6);
         if (ms[2] > 0) printf("  C lds %.3f ms (%.1f G rec/s)", ms[2], gathers / ms[2] / 1e6);
         printf("\n");
         CK(hipFree(buf));
