@@ -60,14 +60,17 @@ def main():
     import ray_tracing_amd as rt
     from ray_tracing_amd import scenes
 
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: take the N>1 code path (RCCL init, reduce, max-over-ranks) with one rank --
+    # the only rehearsal of it a 1-GPU box allows
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +156,7 @@ def main():
         def step(record, all_stages=False):
             _, st = ctx.render(width, height, args.spp, args.depth, args.seed, spp_first,
                                flags=rt.api.RENDER_TIME_STAGES if all_stages else 0, out=acc.data_ptr())
-            if world > 1:
+            if use_dist:
                 dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
             last["st"] = st
             if record:  # k_extend is timed by HIP events on the library's stream in every render call
@@ -190,7 +193,7 @@ def main():
                     f"{width}x{height}, {args.spp} spp, depth {args.depth}")
 
     # max over ranks of the timed region
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -222,10 +225,10 @@ def main():
             "detail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in result.items()
                        if k not in ("kernel", "alg_bytes")},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, desc, scene, width, height)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
