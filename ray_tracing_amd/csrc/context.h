@@ -30,6 +30,17 @@ void set_error(const char* fmt, ...);
 #endif
 #define RT_TRACE_ATTR __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU)))
 #define RT_TRACE_ATTR_ANY __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_ANY)))
+#ifndef RT_WAVES_EU_LEAN
+#define RT_WAVES_EU_LEAN 6  // scenes without analytic sphere/triangle objects (device_trace.h, SceneFeatures)
+#endif
+#ifndef RT_LEAN_FEAT
+#define RT_LEAN_FEAT 1u     // what the lean kernels still support: rtd::FEAT_TRANSFORM
+#endif
+#ifndef RT_WAVES_EU_LEAN_ANY
+#define RT_WAVES_EU_LEAN_ANY 6
+#endif
+#define RT_TRACE_ATTR_LEAN __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_LEAN)))
+#define RT_TRACE_ATTR_LEAN_ANY __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_LEAN_ANY)))
 constexpr int RT_BLOCK = 256;      // threads per workgroup in the traversal kernels (4 waves)
 #ifndef RT_STACK_LDS_N
 #define RT_STACK_LDS_N 24
@@ -39,7 +50,16 @@ constexpr int RT_BLOCK = 256;      // threads per workgroup in the traversal ker
 #endif
 constexpr int RT_STACK_LDS = RT_STACK_LDS_N;  // traversal-stack entries per lane kept in LDS, closest-hit kernels (1 KiB/block each)
 constexpr int RT_STACK_ANY = RT_STACK_ANY_N;  // same for the any-hit kernels
-constexpr int RT_STACK_MIN = RT_STACK_LDS < RT_STACK_ANY ? RT_STACK_LDS : RT_STACK_ANY;
+#ifndef RT_STACK_LEAN_N
+#define RT_STACK_LEAN_N 20
+#endif
+#ifndef RT_STACK_LEAN_ANY_N
+#define RT_STACK_LEAN_ANY_N 20
+#endif
+constexpr int RT_STACK_LEAN = RT_STACK_LEAN_N;          // lean closest-hit kernel: 20 KiB per block (6 blocks per CU)
+constexpr int RT_STACK_LEAN_ANY = RT_STACK_LEAN_ANY_N;  // lean any-hit kernel: the same (7 waves measured no faster than 6)
+constexpr int rt_min_i(int a, int b) { return a < b ? a : b; }
+constexpr int RT_STACK_MIN = rt_min_i(rt_min_i(RT_STACK_LEAN, RT_STACK_LEAN_ANY), rt_min_i(RT_STACK_LDS, RT_STACK_ANY));
 constexpr int RT_TRACE_GRID = 2048;  // workgroups of the grid-stride trace kernels (8 per CU)
 
 struct DevBuf {
@@ -53,6 +73,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool has_scene = false;
+    uint32_t features = 0;  // rtd::SceneFeatures the uploaded scene needs
     rtd::DScene scene{};  // host copy of the kernel argument
     DevBuf pairs, tris, objects, materials, lights, media;
     DevBuf overflow;      // traversal-stack overflow strips

@@ -65,7 +65,13 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
 //   first_is_any(i)                        kind of the ray load() returned
 //   next(i, was_any, got, occluded, vis, &o, &d, &any) -> bool
 //                                          ray of item i finished; true = the lane continues with (o, d, any)
-template <int MODE, bool COUNT, int STACK_LDS, int BLOCK, class IO>
+// FEAT: what the scene's objects can be (SceneFeatures).  The advance phase -- transforms, analytic
+// sphere and triangle objects -- is what sets the register count of the whole loop: 94 VGPRs with
+// everything, 72 with meshes and planes only, i.e. 5 against 7 waves per SIMD.  rt_upload_scene
+// records what the scene uses and the hot kernels exist in a lean and a full instantiation.
+enum SceneFeatures : uint32_t { FEAT_TRANSFORM = 1u, FEAT_SPHERE_TRIANGLE = 2u, FEAT_ALL = 3u };
+
+template <int MODE, bool COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, class IO>
 RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
                        float t_max_in, uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride) {
     constexpr bool PATH = MODE == TRACE_PATH;
@@ -216,7 +222,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                            q2 = ld16(sc.tris, hit_tri * 48u + 32u);
                     V3 nrm = normalise(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));  // primitives.rs:175
                     float t = tmax;
-                    if (ob.has_transform) {
+                    if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {
                         t = t * nr;
                         nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
                     }
@@ -235,7 +241,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     const DObject& ob = sc.objects[obj];
                     o = wo;
                     d = wd;
-                    if (ob.has_transform) {  // object.rs:39-45
+                    if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {  // object.rs:39-45
                         o = mat_mul(ob.inv_m, wo) + v3(ob.inv_t[0], ob.inv_t[1], ob.inv_t[2]);
                         d = mat_mul(ob.inv_m, wd);
                         nr = norm_recip(d);
@@ -266,12 +272,12 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     V3 nrm = wo;
                     uint32_t ff = 0;
                     bool h = false;
-                    if (ob.kind == RT_SURF_SPHERE) {
+                    if ((FEAT & FEAT_SPHERE_TRIANGLE) && ob.kind == RT_SURF_SPHERE) {
                         h = sphere_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), ob.surf[3], o, d, t_min, t_lim, &t, &nrm, &ff);
                     } else if (ob.kind == RT_SURF_PLANE) {
                         nrm = v3(ob.surf[0], ob.surf[1], ob.surf[2]);
                         h = plane_hit(nrm, ob.surf[3], o, d, t_min, t_lim, &t, &ff);
-                    } else if (ob.kind == RT_SURF_TRIANGLE) {
+                    } else if ((FEAT & FEAT_SPHERE_TRIANGLE) && ob.kind == RT_SURF_TRIANGLE) {
                         V3 e1 = v3(ob.surf[3], ob.surf[4], ob.surf[5]), e2 = v3(ob.surf[6], ob.surf[7], ob.surf[8]);
                         float det;
                         h = tri_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), e1, e2, o, d, t_min, t_lim, &t, &det);
@@ -283,7 +289,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                             finish(true);
                             break;
                         }
-                        if (ob.has_transform) {
+                        if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {
                             t = t * nr;
                             nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
                         }

@@ -124,6 +124,17 @@ __global__ RT_TRACE_ATTR void k_trace(DScene sc, TraceIO io, uint32_t n, float t
                                                                         overflow_stride);
 }
 
+// lean form (scenes without analytic sphere / triangle objects, rtd::SceneFeatures): 6 waves per SIMD
+template <bool ANY>
+__global__ RT_TRACE_ATTR_LEAN void k_trace_lean(DScene sc, TraceIO io, uint32_t n, float t_min, float t_max,
+                                                uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
+                                                uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    trace_loop<ANY ? TRACE_ANY : TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT>(
+        sc, io, n, work_counter, tune, t_min, t_max, lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+}
+
 // ---------------------------------------------------------------- helpers
 namespace {
 
@@ -353,6 +364,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
 
     // ---- objects
     std::vector<DObject> objs(s->n_objects);
+    uint32_t features = 0;
     for (uint32_t i = 0; i < s->n_objects; ++i) {
         const rt_object_flat& f = s->objects[i];
         DObject& o = objs[i];
@@ -386,6 +398,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
             }
         }
         o.has_transform = f.has_transform;
+        if (f.has_transform) features |= rtd::FEAT_TRANSFORM;
+        if (f.surface_kind == RT_SURF_SPHERE || f.surface_kind == RT_SURF_TRIANGLE) features |= rtd::FEAT_SPHERE_TRIANGLE;
         memcpy(o.inv_m, f.inv_matrix, sizeof o.inv_m);
         memcpy(o.inv_t, f.inv_translation, sizeof o.inv_t);
         if (f.material >= s->n_materials || f.medium_inside >= (int32_t)s->n_media ||
@@ -446,6 +460,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
     d.initial_medium = s->initial_medium == RT_MEDIUM_AUTO ? RT_MEDIUM_NONE : s->initial_medium;
     d.stack_need = stack_need;
     ctx->overflow_levels = stack_need > (uint32_t)RT_STACK_MIN ? stack_need - RT_STACK_MIN : 0;
+    ctx->features = features;
     ctx->has_scene = true;
 
     if (s->initial_medium == RT_MEDIUM_AUTO) {
@@ -538,6 +553,11 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
                            (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
                            (uint32_t*)ctx->overflow.p,
                            (uint32_t)lanes);
+    else if ((ctx->features & ~RT_LEAN_FEAT) == 0)
+        hipLaunchKernelGGL((k_trace_lean<false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
+                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
+                           (uint32_t*)ctx->overflow.p,
+                           (uint32_t)lanes);
     else
         hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
                            (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
@@ -588,6 +608,11 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
     RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (d_ni || d_nt)
         hipLaunchKernelGGL((k_trace<true, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
+                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
+                           (uint32_t*)ctx->overflow.p,
+                           (uint32_t)lanes);
+    else if ((ctx->features & ~RT_LEAN_FEAT) == 0)
+        hipLaunchKernelGGL((k_trace_lean<true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
                            (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
                            (uint32_t*)ctx->overflow.p,
                            (uint32_t)lanes);

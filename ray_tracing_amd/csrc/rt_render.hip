@@ -132,6 +132,17 @@ __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t*
     if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
 }
 
+// The same kernel for scenes whose objects are meshes and planes (rtd::SceneFeatures): fewer registers, more waves.
+__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n,
+                                                 uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
+                                                 uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    ExtendIO io{pa, queue, 0ull, 0ull};
+    trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+                                                                  lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+}
+
 // ---------------------------------------------------------------- shadow-connect
 struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds its pending NEE term
     PathArrays pa;
@@ -171,6 +182,15 @@ __global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, uint32_t n,
     trace_loop<TRACE_ANY, COUNT, RT_STACK_ANY, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     if (COUNT) add_visits(&pa.visit[2], io.n_int, io.n_tri);
+}
+
+__global__ RT_TRACE_ATTR_LEAN_ANY void k_shadow_lean(DScene sc, PathArrays pa, uint32_t n, uint32_t* work_counter,
+                                                     TraceTune tune, uint32_t* overflow, uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LEAN_ANY * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    ShadowIO io{pa, 0ull, 0ull};
+    trace_loop<TRACE_ANY, false, RT_STACK_LEAN_ANY, RT_BLOCK, RT_LEAN_FEAT>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+                                                              lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
 
 // ---------------------------------------------------------------- shade
@@ -675,6 +695,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
 
     const bool count = (flags & RT_RENDER_COUNT_VISITS) != 0;
     const bool use_tail = (flags & RT_RENDER_NO_TAIL) == 0;
+    // scenes without analytic sphere / triangle objects (meshes, planes, transforms) take the lean kernels
+    const bool lean = (ctx->features & ~RT_LEAN_FEAT) == 0 && getenv("RT_NO_LEAN") == nullptr;
     static const uint32_t tail_paths = [] {  // RT_TAIL_PATHS overrides the switch-over point (experiments)
         const char* e = getenv("RT_TAIL_PATHS");
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 32768u;
@@ -771,6 +793,9 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             if (count)
                 hipLaunchKernelGGL(k_extend<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
                                    pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
+            else if (lean)
+                hipLaunchKernelGGL(k_extend_lean, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, pa.queue[cur],
+                                   n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
             else
                 hipLaunchKernelGGL(k_extend<false>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
                                    pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
@@ -805,6 +830,9 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                 if ((rc = t_begin(3)) != RT_OK) return rc;
                 if (count)
                     hipLaunchKernelGGL(k_shadow<true>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
+                                       pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
+                else if (lean)
+                    hipLaunchKernelGGL(k_shadow_lean, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
                                        pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
                 else
                     hipLaunchKernelGGL(k_shadow<false>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
