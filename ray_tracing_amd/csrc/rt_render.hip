@@ -30,18 +30,17 @@ constexpr float T_MIN = 1e-3f;  // path_integrator.rs:15
 constexpr int SHADE_BLOCK = 256;
 
 constexpr uint32_t QF_ALIVE = 1u, QF_SHADOW = 2u;
-constexpr uint32_t PF_PREV_SPECULAR = 1u;
 
 struct PathArrays {      // SoA over slots
-    float4* ray_o;       // origin.xyz, -
+    // 16-byte records; the w lanes carry the scalar path state, so a bounce moves 3 records per path
+    // in and 3 out (the bounce number is the wavefront iteration: a kernel argument, not path state)
+    float4* ray_o;       // origin.xyz, bits: current medium (int) << 1 | previous bounce was specular
     float4* ray_d;       // direction.xyz, prev_pdf
-    float4* beta;        // throughput.xyz, -
+    float4* beta;        // throughput.xyz, bits: depth (u32; wraps like the reference's, path_integrator.rs:193)
     float4* rad;         // radiance.xyz, -
-    uint4* meta;         // depth, bounce, current medium (int), flags
     float4* hit_a;       // t, normal.xyz
     uint2* hit_b;        // obj | front_face<<31 (RT_MISS = no hit), prim
-    float4* sh_o;        // shadow origin.xyz, -
-    float4* sh_d;        // shadow direction.xyz, -
+    float4* sh_d;        // shadow direction.xyz, - (the shadow ray starts at ray_o: the vertex just shaded)
     float4* sh_c;        // pending NEE term.xyz, apply flag
     uint32_t* queue[2];  // live-path queues (ping-pong)
     uint32_t* shadow_q;
@@ -61,7 +60,11 @@ struct RenderParams {
     uint32_t sample_first;  // global index of sample_in_batch 0
     uint32_t depth;
     uint32_t k0, k1;        // Philox key = seed
+    uint32_t bounce;        // k_shade: RNG bounce index of this wavefront iteration (= iteration + 1)
 };
+RT_DEV float pack_medium(int medium, bool prev_specular) {
+    return __uint_as_float(((uint32_t)medium << 1) | (prev_specular ? 1u : 0u));
+}
 
 // ---------------------------------------------------------------- generate
 __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, RenderParams rp, uint32_t n_paths) {
@@ -76,11 +79,11 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
     V3 origin = ld3(sc.camera.origin);
     V3 dir = ld3(sc.camera.lower_left_corner) + u * ld3(sc.camera.horizontal) + v * ld3(sc.camera.vertical) - origin;
     dir = normalise(dir);  // camera.rs:60-63
-    pa.ray_o[slot] = make_float4(origin.x, origin.y, origin.z, 0.0f);
-    pa.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);  // prev_pdf = 1 (:147)
-    pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    // :139-148: beta = 1, radiance = 0, prev_pdf = 1, prev_specular = true, current medium = initial
+    pa.ray_o[slot] = make_float4(origin.x, origin.y, origin.z, pack_medium(sc.initial_medium, true));
+    pa.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
+    pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rp.depth));
     pa.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    pa.meta[slot] = make_uint4(rp.depth, 0u, (uint32_t)sc.initial_medium, PF_PREV_SPECULAR);  // :139-148
     pa.queue[0][slot] = slot;
 }
 
@@ -149,7 +152,7 @@ struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds it
     unsigned long long n_int, n_tri;
     RT_DEV void load(uint32_t i, V3* o, V3* d) const {
         const uint32_t slot = pa.shadow_q[i];
-        float4 o4 = pa.sh_o[slot], d4 = pa.sh_d[slot];
+        float4 o4 = pa.ray_o[slot], d4 = pa.sh_d[slot];
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
     }
@@ -202,17 +205,17 @@ RT_DEV float mis_weight(float pa, float pb) {  // path_integrator.rs:30-39, powe
 }
 
 // One iteration of the loop body of ray_colour for the path in `slot`.  Returns QF_* flags.
-RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot) {
-    uint4 meta = pa.meta[slot];
-    uint32_t depth = meta.x, bounce = meta.y;
-    int medium = (int)meta.z;
-    bool prev_specular = (meta.w & PF_PREV_SPECULAR) != 0;
+RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot,
+                           uint32_t bounce) {
     float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot], b4 = pa.beta[slot];
     V3 ro = v3(o4.x, o4.y, o4.z), rd = v3(d4.x, d4.y, d4.z), beta = v3(b4.x, b4.y, b4.z);
     float prev_pdf = d4.w;
+    uint32_t depth = __float_as_uint(b4.w);
+    const uint32_t mbits = __float_as_uint(o4.w);
+    int medium = (int)mbits >> 1;
+    bool prev_specular = (mbits & 1u) != 0;
 
     depth -= 1;  // `while depth > 0 { depth -= 1;` (:150-151)
-    bounce += 1;
     uint32_t pixel = slot % rp.npix;
     Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + slot / rp.npix, bounce, 0u};
 
@@ -269,10 +272,9 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         } else {
             depth -= 1;  // u32, wraps at 0 exactly like the release-mode reference (:193)
             beta = beta * (transmittance * mi.f / mi.pdf);
-            pa.ray_o[slot] = make_float4(mi.origin.x, mi.origin.y, mi.origin.z, 0.0f);
+            pa.ray_o[slot] = make_float4(mi.origin.x, mi.origin.y, mi.origin.z, o4.w);
             pa.ray_d[slot] = make_float4(mi.dir.x, mi.dir.y, mi.dir.z, prev_pdf);
-            pa.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
-            pa.meta[slot] = make_uint4(depth, bounce, (uint32_t)medium, meta.w);
+            pa.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(depth));
             return depth > 0 ? QF_ALIVE : 0;  // `continue`
         }
     }
@@ -298,7 +300,6 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         float p_bsdf = bsdf_pdf(mat, wi_local, wo_local);
         float w = mis_weight(p_light, p_bsdf);
         V3 add = (w * mul_elemwise(beta, contribution)) / p_light;
-        pa.sh_o[slot] = make_float4(interaction_point.x, interaction_point.y, interaction_point.z, 0.0f);
         pa.sh_d[slot] = make_float4(ls.direction.x, ls.direction.y, ls.direction.z, 0.0f);
         pa.sh_c[slot] = make_float4(add.x, add.y, add.z, p_light > 0.0f ? 1.0f : 0.0f);
         flags |= QF_SHADOW;
@@ -315,13 +316,15 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
 
     // Russian roulette (:263-272)
     float q = 1.0f - max_elem(beta);
-    if (rng.f32() < q) return flags;
+    const bool survives = !(rng.f32() < q);
+    // the vertex is the origin of the next ray AND of the pending shadow ray: written if either exists
+    if (survives || (flags & QF_SHADOW))
+        pa.ray_o[slot] = make_float4(interaction_point.x, interaction_point.y, interaction_point.z,
+                                     pack_medium(medium, bs.is_specular));
+    if (!survives) return flags;
     beta = div_assign(beta, 1.0f - q);
-
-    pa.ray_o[slot] = make_float4(interaction_point.x, interaction_point.y, interaction_point.z, 0.0f);
     pa.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, prev_pdf);
-    pa.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
-    pa.meta[slot] = make_uint4(depth, bounce, (uint32_t)medium, bs.is_specular ? PF_PREV_SPECULAR : 0u);
+    pa.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(depth));
     if (depth > 0) flags |= QF_ALIVE;
     return flags;
 }
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
     uint32_t flags = 0;
     if (i < n) {
-        flags = shade_path(sc, pa, rp, queue[i]);
+        flags = shade_path(sc, pa, rp, queue[i], rp.bounce);
         pa.qflags[i] = flags;
     }
     // block totals for the compaction scan (wave ballots)
@@ -405,10 +408,10 @@ struct TailIO {
             n_int += vis.n_int;
             n_tri += vis.n_tri;
             if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
-            const uint32_t flags = shade_path(*sc, pa, *rp, slot);
+            const uint32_t flags = shade_path(*sc, pa, *rp, slot, rp->bounce + iters - 1u);
             alive_after = (flags & QF_ALIVE) != 0;
             if (flags & QF_SHADOW) {
-                float4 o4 = pa.sh_o[slot], d4 = pa.sh_d[slot];
+                float4 o4 = pa.ray_o[slot], d4 = pa.sh_d[slot];
                 *o = v3(o4.x, o4.y, o4.z);
                 *d = v3(d4.x, d4.y, d4.z);
                 *any = true;
@@ -622,13 +625,13 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     // ---- batch size: samples in flight at once.  Every wavefront iteration ends in a tail of
     // half-empty waves and a host round trip, so the batch is made as large as memory allows
     // (measured at 1080p/32 spp: 8 Mi paths 145 ms, 64 Mi paths 71 ms): by default up to 40 % of
-    // the free HBM, ~180 B per path slot.
+    // the free HBM, ~148 B per path slot.
     uint64_t max_paths = ctx->max_paths_in_flight;
     if (max_paths == 0) {
         size_t free_b = 0, total_b = 0;
         RT_HIP(hipMemGetInfo(&free_b, &total_b));
         free_b += ctx->path_state.bytes;  // our own previous allocation is reusable
-        max_paths = (uint64_t)((double)free_b * 0.4 / 180.0);
+        max_paths = (uint64_t)((double)free_b * 0.4 / 148.0);
         if (max_paths < ((uint64_t)1 << 20)) max_paths = (uint64_t)1 << 20;
     }
     uint32_t s_batch = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
@@ -645,8 +648,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         return o;
     };
     size_t o_ray_o = carve(P * 16), o_ray_d = carve(P * 16), o_beta = carve(P * 16), o_rad = carve(P * 16),
-           o_meta = carve(P * 16), o_hit_a = carve(P * 16), o_hit_b = carve(P * 8), o_sh_o = carve(P * 16),
-           o_sh_d = carve(P * 16), o_sh_c = carve(P * 16), o_q0 = carve(P * 4), o_q1 = carve(P * 4),
+           o_hit_a = carve(P * 16), o_hit_b = carve(P * 8), o_sh_d = carve(P * 16), o_sh_c = carve(P * 16), o_q0 = carve(P * 4), o_q1 = carve(P * 4),
            o_sq = carve(P * 4), o_qf = carve(P * 4), o_bc = carve((size_t)max_blocks * 8),
            o_bo = carve((size_t)max_blocks * 8), o_gt = carve(((size_t)max_blocks / 1024 + 1) * 8),
            o_go = carve(((size_t)max_blocks / 1024 + 1) * 8), o_tot = carve(256), o_vis = carve(256), o_tail = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
@@ -658,10 +660,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     pa.ray_d = (float4*)(base + o_ray_d);
     pa.beta = (float4*)(base + o_beta);
     pa.rad = (float4*)(base + o_rad);
-    pa.meta = (uint4*)(base + o_meta);
     pa.hit_a = (float4*)(base + o_hit_a);
     pa.hit_b = (uint2*)(base + o_hit_b);
-    pa.sh_o = (float4*)(base + o_sh_o);
     pa.sh_d = (float4*)(base + o_sh_d);
     pa.sh_c = (float4*)(base + o_sh_c);
     pa.queue[0] = (uint32_t*)(base + o_q0);
@@ -770,6 +770,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
             const int tgrid = (int)std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
             RT_HIP(hipMemsetAsync(pa.work, 0, 2 * rtd::WORK_U32 * 4, stream));
+            rp.bounce = iter + 1;  // iteration k of `while depth > 0` draws from RNG bounce k+1 (bounce 0: camera jitter)
             if (use_tail && n <= tail_paths) {  // few paths left: one launch takes them to their end
                 RT_HIP(hipMemsetAsync(pa.tail + 6, 0, 8, stream));
                 if ((rc = t_begin(5)) != RT_OK) return rc;
