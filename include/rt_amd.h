@@ -282,8 +282,9 @@ typedef struct rt_stats {
     float ms_generate, ms_extend, ms_shade, ms_shadow, ms_compact;
     uint64_t launches_extend; /* number of extend launches (for per-launch averages) */
     uint64_t launches_shadow;
-    /* Share of the totals above that the tail kernel handled: once fewer than a threshold of paths
-       are alive, ONE launch carries each of them through all its remaining bounces. */
+    /* Share of the totals above traced outside the per-bounce extend / shadow launches: late
+       bounces trace their shadow rays and the next bounce's rays in one launch, and once few paths are
+       alive ONE launch carries each of them through all its remaining bounces (paths_tail). */
     uint64_t paths_tail;
     uint64_t rays_closest_tail, rays_shadow_tail;
     uint64_t nodes_visited_tail, tris_tested_tail; /* closest-hit rays of the tail kernel */

@@ -462,6 +462,83 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, Ren
     }
 }
 
+// ---------------------------------------------------------------- mixed (late bounces)
+// Late in a frame a traversal launch lasts as long as its longest ray (~0.35 ms) however few rays it
+// has, and a bounce has two of them: the shadow rays of bounce k, then the rays of bounce k+1.  Neither
+// depends on the other (one adds to the radiance, the other writes hit records; both only read the
+// vertex in ray_o), so below RT_MIX_PATHS rays they share ONE launch: items [0, n_shadow) are the shadow
+// queue, items [n_shadow, n_shadow + n_next) the live-path queue.  k_shade of bounce k+1 still runs after
+// both, so the order of additions into a path's radiance is unchanged.
+struct MixedIO {
+    PathArrays pa;
+    const uint32_t* queue;  // live paths of the NEXT bounce
+    uint32_t n_shadow;
+    unsigned long long n_int, n_tri, n_int_sh, n_tri_sh;
+    RT_DEV bool first_is_any(uint32_t i) const { return i < n_shadow; }
+    RT_DEV void load(uint32_t i, V3* o, V3* d) const {
+        const bool sh = i < n_shadow;
+        const uint32_t slot = sh ? pa.shadow_q[i] : queue[i - n_shadow];
+        float4 o4 = pa.ray_o[slot], d4 = sh ? pa.sh_d[slot] : pa.ray_d[slot];
+        *o = v3(o4.x, o4.y, o4.z);
+        *d = v3(d4.x, d4.y, d4.z);
+    }
+    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
+        const uint32_t slot = queue[i - n_shadow];
+        pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
+        pa.hit_b[slot] = make_uint2(meta, prim);
+    }
+    RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
+    RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
+    RT_DEV bool next(uint32_t i, bool was_any, bool got, bool occluded, const Visits& vis, V3*, V3*, bool*) {
+        if (was_any) {
+            n_int_sh += vis.n_int;
+            n_tri_sh += vis.n_tri;
+            if (!occluded) {
+                const uint32_t slot = pa.shadow_q[i];
+                float4 c = pa.sh_c[slot];
+                if (c.w != 0.0f) {  // p_light > 0 (path_integrator.rs:234)
+                    float4 r = pa.rad[slot];
+                    r.x += c.x;
+                    r.y += c.y;
+                    r.z += c.z;
+                    pa.rad[slot] = r;
+                }
+            }
+        } else {
+            n_int += vis.n_int;
+            n_tri += vis.n_tri;
+            if (!got) pa.hit_b[queue[i - n_shadow]] = make_uint2(RT_MISS, RT_MISS);
+        }
+        return false;
+    }
+};
+
+template <bool COUNT>
+__global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n_shadow, uint32_t n,
+                                      uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
+                                      uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    MixedIO io{pa, queue, n_shadow, 0ull, 0ull, 0ull, 0ull};
+    trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    if (COUNT) {  // accounted with the tail kernel's share: rays traced outside k_extend / k_shadow
+        add_visits(&pa.tail[2], io.n_int, io.n_tri);
+        add_visits(&pa.tail[4], io.n_int_sh, io.n_tri_sh);
+    }
+}
+
+__global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n_shadow,
+                                                uint32_t n, uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
+                                                uint32_t overflow_stride) {
+    __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    MixedIO io{pa, queue, n_shadow, 0ull, 0ull, 0ull, 0ull};
+    trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT>(sc, io, n, work_counter, tune, T_MIN,
+                                                                         __builtin_inff(), lds_stack + threadIdx.x,
+                                                                         overflow + gtid, overflow_stride);
+}
+
 // ---------------------------------------------------------------- compact
 // Exclusive scan of the per-block totals in two levels, both queues (alive, shadow) at once:
 //   k_compact_scan_groups: one workgroup per 1024 consecutive shade blocks -- coalesced read, wave
@@ -696,6 +773,12 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     const bool count = (flags & RT_RENDER_COUNT_VISITS) != 0;
     const bool use_tail = (flags & RT_RENDER_NO_TAIL) == 0;
     // scenes without analytic sphere / triangle objects (meshes, planes, transforms) take the lean kernels
+    static const uint64_t mix_paths = [] {  // RT_MIX_PATHS: rays (shadow + next bounce) up to which they share a launch
+        const char* e = getenv("RT_MIX_PATHS");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)4194304;
+    }();
+    const bool use_mix = use_tail && mix_paths > 0;
+    uint64_t mixed_closest = 0, mixed_shadow = 0;
     const bool lean = (ctx->features & ~RT_LEAN_FEAT) == 0 && getenv("RT_NO_LEAN") == nullptr;
     static const uint32_t tail_paths = [] {  // RT_TAIL_PATHS overrides the switch-over point (experiments)
         const char* e = getenv("RT_TAIL_PATHS");
@@ -762,6 +845,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         uint32_t n = depth > 0 ? n_paths : 0;
         int cur = 0;
         uint32_t iter = 0;
+        bool extend_done = false;  // the rays of this bounce were traced by the previous bounce's mixed launch
         while (n > 0) {
             if (iter >= 1u << 20) {
                 rth::set_error("rt_render: wavefront did not drain after 2^20 iterations");
@@ -790,6 +874,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                 iter += (uint32_t)tail_iters;
                 break;
             }
+            if (!extend_done) {
             if ((rc = t_begin(1)) != RT_OK) return rc;
             if (count)
                 hipLaunchKernelGGL(k_extend<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
@@ -803,6 +888,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             if ((rc = t_end(1)) != RT_OK) return rc;
             st.rays_closest += n;
             st.launches_extend += 1;
+            }
+            extend_done = false;
 
             if ((rc = t_begin(2)) != RT_OK) return rc;
             hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pa, rp,
@@ -826,7 +913,32 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                 rth::set_error("rt_render: compaction produced impossible counts");
                 return RT_ERR_HIP;
             }
-            if (n_shadow > 0) {
+            const bool tail_next = use_tail && n_next <= tail_paths;  // the tail kernel traces its own first ray
+            if (use_mix && n_shadow > 0 && n_next > 0 && !tail_next && (uint64_t)n_shadow + n_next <= mix_paths) {
+                // the shadow rays of this bounce and the rays of the next one in one launch
+                const uint32_t n_mix = n_shadow + n_next;
+                const int mgrid = (int)std::min<uint32_t>((n_mix + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
+                if ((rc = t_begin(5)) != RT_OK) return rc;
+                if (count)
+                    hipLaunchKernelGGL(k_mixed<true>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                                       pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
+                                       rt_trace_tune(n_mix, mgrid), overflow, ostride);
+                else if (lean)
+                    hipLaunchKernelGGL(k_mixed_lean, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                                       pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
+                                       rt_trace_tune(n_mix, mgrid), overflow, ostride);
+                else
+                    hipLaunchKernelGGL(k_mixed<false>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                                       pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
+                                       rt_trace_tune(n_mix, mgrid), overflow, ostride);
+                if ((rc = t_end(5)) != RT_OK) return rc;
+                st.rays_shadow += n_shadow;
+                st.rays_closest += n_next;
+                mixed_closest += n_next;
+                mixed_shadow += n_shadow;
+                st.launches_tail += 1;
+                extend_done = true;
+            } else if (n_shadow > 0) {
                 const int sgrid = (int)std::min<uint32_t>((n_shadow + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
                 if ((rc = t_begin(3)) != RT_OK) return rc;
                 if (count)
@@ -855,13 +967,13 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     RT_HIP(hipEventRecord(ctx->ev[1], stream));
     unsigned long long visit[4] = {0, 0, 0, 0}, tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (count) RT_HIP(hipMemcpyAsync(visit, pa.visit, sizeof visit, hipMemcpyDeviceToHost, stream));
-    if (st.launches_tail) RT_HIP(hipMemcpyAsync(tail, pa.tail, sizeof tail, hipMemcpyDeviceToHost, stream));
+    if (st.launches_tail) RT_HIP(hipMemcpyAsync(tail, pa.tail, sizeof tail, hipMemcpyDeviceToHost, stream));  // tail and mixed launches
     if (host_out) RT_HIP(hipMemcpyAsync(rgb_sum, d_sum, sum_bytes, hipMemcpyDeviceToHost, stream));
     RT_HIP(hipStreamSynchronize(stream));
     if ((rc = t_collect()) != RT_OK) return rc;
     RT_HIP(hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[1]));
-    st.rays_closest_tail = tail[0];
-    st.rays_shadow_tail = tail[1];
+    st.rays_closest_tail = tail[0] + mixed_closest;
+    st.rays_shadow_tail = tail[1] + mixed_shadow;
     st.nodes_visited_tail = tail[2];
     st.tris_tested_tail = tail[3];
     st.rays_closest += tail[0];

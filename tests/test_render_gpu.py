@@ -58,6 +58,15 @@ def test_config2_scene_point_light(ctx):
     assert img.mean() > 0 and st.rays_shadow > 0
 
 
+def test_mid_size_frame_takes_wavefront_mixed_and_tail_launches(ctx):
+    """230 400 paths: above the tail threshold at first (wavefront rounds), few enough that the shadow rays of
+    a bounce share a launch with the rays of the next one (k_mixed), then the tail kernel -- against the
+    oracle and against the plain wavefront pipeline (inside _check)."""
+    img, st, _ = _check(ctx, scenes.path_scene(levels=5, glass_levels=3), 320, 180, 4, 16, seed=9)
+    assert st.launches_extend >= 1 and st.launches_tail >= 2
+    assert 0 < st.rays_closest_tail < st.rays_closest
+
+
 def test_config3_scene_area_light_dielectric(ctx):
     img, st, _ = _check(ctx, scenes.path_scene(levels=5, glass_levels=3), 96, 54, 4, 16, seed=3)
     assert img.mean() > 0 and st.iterations > 4
