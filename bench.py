@@ -181,7 +181,7 @@ def main():
                            + 40 * (st_count.tris_tested - st_count.tris_tested_tail))
         launches = max(1, int(np.mean(ext_launches)))
         ms_extend_timed = float(np.mean(ext_ms))  # average over the K timed frames
-        result.update(kernel="k_extend", kernel_ms=ms_extend_timed / launches, alg_bytes=alg_bytes_total / launches,
+        result.update(kernel="k_extend_lean" if st.lean_kernels else "k_extend", kernel_ms=ms_extend_timed / launches, alg_bytes=alg_bytes_total / launches,
                       launches=int(launches), ms_extend=ms_extend_timed, ms_shadow=st.ms_shadow, ms_shade=st.ms_shade,
                       ms_generate=st.ms_generate, ms_compact=st.ms_compact, ms_tail=st.ms_tail,
                       paths_tail=int(st.paths_tail), ms_device_total=st.ms_total,

@@ -290,7 +290,7 @@ typedef struct rt_stats {
     uint64_t nodes_visited_tail, tris_tested_tail; /* closest-hit rays of the tail kernel */
     uint64_t launches_tail;
     float ms_tail;            /* always filled, like ms_extend */
-    uint32_t reserved;
+    uint32_t lean_kernels;    /* 1: the scene has no analytic sphere/triangle objects and the lean traversal kernels (k_*_lean) ran */
 } rt_stats;
 
 #define RT_RENDER_COUNT_VISITS 1u /* fill nodes_visited / tris_tested (slower kernel variant) */

@@ -983,6 +983,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     st.nodes_visited_shadow = visit[2] + tail[4];
     st.tris_tested_shadow = visit[3] + tail[5];
     st.ms_tail = tm[5].ms;
+    st.lean_kernels = lean ? 1u : 0u;
     st.ms_generate = tm[0].ms;
     st.ms_extend = tm[1].ms;
     st.ms_shade = tm[2].ms;
