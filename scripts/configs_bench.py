@@ -1,0 +1,28 @@
+"""Frame time and Mrays/s of every BASELINE.json config on one GPU (bench.py measures configs[2] only)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ray_tracing_amd as rt
+from ray_tracing_amd import scenes
+
+def run(name, desc, w, spp, depth=16, reps=2):
+    t0 = time.time(); scene = rt.Scene(desc); t_build = time.time() - t0
+    ctx = rt.Context(0); ctx.upload(scene)
+    h = scenes.image_height(w)
+    acc = torch.zeros(h, w, 3, device="cuda")
+    best = None
+    for _ in range(reps + 1):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _, st = ctx.render(w, h, spp, depth, 0, 0, out=acc.data_ptr())
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    rays = st.rays_closest + st.rays_shadow
+    print(f"{name:34s} {scene.flat.n_tris:9d} tris {scene.flat.n_objects:3d} objects  {w}x{h} {spp:4d} spp  {best*1e3:9.1f} ms/frame "
+          f"{rays/best/1e6:8.1f} Mrays/s  ({rays/1e6:.1f} M rays, {st.batches} batch(es), lean={st.lean_kernels}, scene build {t_build:.1f} s)", flush=True)
+    ctx.close()
+
+run("config 1 volumetric sphere", scenes.volumetric_sphere(), 400, 256)
+run("config 3 path tracing", scenes.path_scene(levels=9), 1920, 64)
+run("config 4 + homogeneous medium", scenes.path_scene(levels=9, medium=True, sigma_s=0.02), 1920, 64)
+run("config 5 10 x 1M-triangle meshes", scenes.multi_mesh_scene(levels=9, copies=10), 1920, 64)
+run("config 5 at 3840x2160, 64 spp", scenes.multi_mesh_scene(levels=9, copies=10), 3840, 64, reps=1)
