@@ -7,7 +7,7 @@
 //   * a launch is a fixed number of waves that PULL rays from work counters, so the chip stays
 //     full until the queue is empty;
 //   * each lane is a small state machine (advance-object / internal node / leaf) and an idle lane
-//     is refilled with a new ray as soon as >= refill_min lanes of its wave are idle, so one long
+//     is refilled with a new ray as soon as >= refill_min (24) lanes of its wave are idle, so one long
 //     ray no longer parks 63 lanes;
 //   * per ray the arithmetic and the visiting order are still exactly those of
 //     Engine::hit -> Object::hit -> traverse_bvh (path_integrator.rs:88-104, object.rs:32-87,
@@ -130,6 +130,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         // ---------------------------------------------------------------- refill idle lanes
         // The wave owns a pool [pool_next, pool_end) of consecutive ray indices; idle lanes draw
         // from it, and it is restocked `chunk` rays at a time from the launch's work counters.
+        bool refilled = false;  // wave-uniform: lanes received new rays in this iteration
         if (more) {
             const bool idle = ray == RAY_NONE;
             const unsigned long long m = __ballot(idle);
@@ -163,6 +164,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                         begin_ray();
                     }
                     pool_next += take;
+                    refilled = take > 0u;
                 }
             }
         }
@@ -183,8 +185,14 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         // TRACE_PATH: continuations go first once a fifth of the busy lanes wait for one (running every
         // phase in every iteration instead was measured slower: 6.3 ms against 4.0 ms for 219 000 paths)
         const bool run_done = PATH && n_done > 0u && 4u * n_done >= n_adv + n_node + n_leaf;
-        const bool run_node = !run_done && n_node > 0u && s_node >= s_leaf && s_node >= s_adv;
-        const bool run_leaf = !run_done && !run_node && n_leaf > 0u && s_leaf >= s_adv;
+#ifndef RT_ADV_AT_REFILL
+#define RT_ADV_AT_REFILL 1
+#endif
+        // new rays start with an advance (first object); run it at once for the lanes just refilled (>= refill_min
+        // of them, plus whoever finished a tree) instead of letting them wait until advance lanes outweigh node lanes
+        const bool adv_now = RT_ADV_AT_REFILL && refilled;
+        const bool run_node = !run_done && !adv_now && n_node > 0u && s_node >= s_leaf && s_node >= s_adv;
+        const bool run_leaf = !run_done && !adv_now && !run_node && n_leaf > 0u && s_leaf >= s_adv;
         const bool run_adv = !run_done && !run_node && !run_leaf;
 #if RT_TRACE_STATS
         if (lane == 0) {

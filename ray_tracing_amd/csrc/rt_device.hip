@@ -40,15 +40,15 @@ TraceTune rt_trace_tune(size_t n, int grid) {
     static unsigned v[6] = {0, 0, 0, 0, 0, 0};
     static bool have_env = false;
     if (v[1] == 0) {
-        unsigned d[6] = {0, 16, 1, 2, 3, WORK_MAX_SEG};
+        unsigned d[6] = {0, 24, 1, 3, 4, WORK_MAX_SEG};
         const char* e = getenv("RT_TUNE");
         if (e) {
             sscanf(e, "%u,%u,%u,%u,%u,%u", &d[0], &d[1], &d[2], &d[3], &d[4], &d[5]);
             have_env = true;
         }
         if (d[0] > 4096) d[0] = 0;
-        if (d[1] == 0 || d[1] > 64) d[1] = 16;
-        if (!d[2] || !d[3] || !d[4]) d[2] = 1, d[3] = 2, d[4] = 3;
+        if (d[1] == 0 || d[1] > 64) d[1] = 24;
+        if (!d[2] || !d[3] || !d[4]) d[2] = 1, d[3] = 3, d[4] = 4;
         if (d[5] == 0 || d[5] > WORK_MAX_SEG) d[5] = WORK_MAX_SEG;
         for (int i = 0; i < 6; ++i) v[i] = d[i];
     }
