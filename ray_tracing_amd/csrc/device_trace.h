@@ -239,14 +239,31 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     io.hit(ray, t, nrm, obj | (hit_ff ? 0x80000000u : 0u), __float_as_uint(q0.w));
                     obj_hit = false;
                 }
-                for (;;) {  // Engine::hit's loop over objects (path_integrator.rs:90-95)
-                    obj = fresh ? 0u : obj + 1u;
-                    fresh = false;
-                    if (obj >= sc.n_objects) {
+            }
+            // Engine::hit's loop over objects (path_integrator.rs:90-95), walked by the WAVE: each step takes
+            // the next object index k of its first waiting lane and serves every lane waiting for that
+            // same k, so the object record is read through a uniform address (scalar registers) instead
+            // of one copy per lane -- a lane still meets the objects in vector order.
+            uint32_t next = fresh ? 0u : obj + 1u;
+            bool pending = adv;
+            if (adv) fresh = false;
+            for (;;) {
+                const unsigned long long pm = __ballot(pending);
+                if (pm == 0ull) break;
+                const uint32_t first = (uint32_t)__builtin_ctzll(pm);
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)next, (int)first);
+                const bool mine = pending && next == k;
+                if (k >= sc.n_objects) {  // uniform
+                    if (mine) {
                         finish(false);
-                        break;
+                        pending = false;
                     }
-                    const DObject& ob = sc.objects[obj];
+                    continue;
+                }
+                const DObject& ob = sc.objects[k];
+                if (mine) {
+                    obj = k;
+                    next = k + 1u;
                     o = wo;
                     d = wd;
                     if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {  // object.rs:39-45
@@ -267,43 +284,48 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                         // either case: the result is identical, one node visit and two phase changes
                         // cheaper.  Not applied when counting visits (those stay the reference's) or
                         // when the root is itself a leaf.
+                        bool enter = true;
                         if (!COUNT && (ob.root_ref & LEAF_BIT) == 0u) {
                             float t_entry;
-                            if (!aabb_hit(&ob.surf[0], &ob.surf[3], o, inv, t_min, t_lim, &t_entry)) continue;
+                            enter = aabb_hit(&ob.surf[0], &ob.surf[3], o, inv, t_min, t_lim, &t_entry);
                         }
-                        tmax = t_lim;
-                        cur = ob.root_ref;
-                        st.sp = 0;
-                        break;
-                    }
-                    float t = 0.0f;
-                    V3 nrm = wo;
-                    uint32_t ff = 0;
-                    bool h = false;
-                    if ((FEAT & FEAT_SPHERE_TRIANGLE) && ob.kind == RT_SURF_SPHERE) {
-                        h = sphere_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), ob.surf[3], o, d, t_min, t_lim, &t, &nrm, &ff);
-                    } else if (ob.kind == RT_SURF_PLANE) {
-                        nrm = v3(ob.surf[0], ob.surf[1], ob.surf[2]);
-                        h = plane_hit(nrm, ob.surf[3], o, d, t_min, t_lim, &t, &ff);
-                    } else if ((FEAT & FEAT_SPHERE_TRIANGLE) && ob.kind == RT_SURF_TRIANGLE) {
-                        V3 e1 = v3(ob.surf[3], ob.surf[4], ob.surf[5]), e2 = v3(ob.surf[6], ob.surf[7], ob.surf[8]);
-                        float det;
-                        h = tri_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), e1, e2, o, d, t_min, t_lim, &t, &det);
-                        nrm = normalise(cross(e1, e2));
-                        ff = det > 0.0f;
-                    }
-                    if (h) {
-                        if (any) {
-                            finish(true);
-                            break;
+                        if (enter) {
+                            tmax = t_lim;
+                            cur = ob.root_ref;
+                            st.sp = 0;
+                            pending = false;
                         }
-                        if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {
-                            t = t * nr;
-                            nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
+                    } else {
+                        float t = 0.0f;
+                        V3 nrm = wo;
+                        uint32_t ff = 0;
+                        bool h = false;
+                        if ((FEAT & FEAT_SPHERE_TRIANGLE) && ob.kind == RT_SURF_SPHERE) {
+                            h = sphere_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), ob.surf[3], o, d, t_min, t_lim, &t, &nrm, &ff);
+                        } else if (ob.kind == RT_SURF_PLANE) {
+                            nrm = v3(ob.surf[0], ob.surf[1], ob.surf[2]);
+                            h = plane_hit(nrm, ob.surf[3], o, d, t_min, t_lim, &t, &ff);
+                        } else if ((FEAT & FEAT_SPHERE_TRIANGLE) && ob.kind == RT_SURF_TRIANGLE) {
+                            V3 e1 = v3(ob.surf[3], ob.surf[4], ob.surf[5]), e2 = v3(ob.surf[6], ob.surf[7], ob.surf[8]);
+                            float det;
+                            h = tri_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), e1, e2, o, d, t_min, t_lim, &t, &det);
+                            nrm = normalise(cross(e1, e2));
+                            ff = det > 0.0f;
                         }
-                        best_t = t;
-                        got = true;
-                        io.hit(ray, t, nrm, obj | (ff << 31), 0u);
+                        if (h) {
+                            if (any) {
+                                finish(true);
+                                pending = false;
+                            } else {
+                                if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {
+                                    t = t * nr;
+                                    nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
+                                }
+                                best_t = t;
+                                got = true;
+                                io.hit(ray, t, nrm, obj | (ff << 31), 0u);
+                            }
+                        }
                     }
                 }
             }
