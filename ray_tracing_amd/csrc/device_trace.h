@@ -344,17 +344,12 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                 float t1, t2;
                 const bool h1 = aabb_hit(lo1, hi1, o, inv, t_min, tmax, &t1);
                 const bool h2 = aabb_hit(lo2, hi2, o, inv, t_min, tmax, &t2);
-                if (h1 && h2) {  // bvh.rs:287-295: far pushed, near next; near = child1 unless t1 > t2
-                    const bool swap = t1 > t2;
-                    st.push(swap ? ref1 : ref2);
-                    cur = swap ? ref2 : ref1;
-                } else if (h1) {
-                    cur = ref1;
-                } else if (h2) {
-                    cur = ref2;
-                } else {
-                    cur = st.sp == 0 ? REF_ADVANCE : st.pop();
-                }
+                // bvh.rs:287-295: both hit -> far pushed, near next, near = child1 unless t1 > t2; one hit -> that
+                // child; none -> pop.  Written as two predicated regions instead of a four-way branch.
+                const bool swap = t1 > t2;
+                cur = (h2 && (!h1 || swap)) ? ref2 : ref1;
+                if (h1 && h2) st.push(swap ? ref1 : ref2);
+                if (!(h1 || h2)) cur = st.sp == 0 ? REF_ADVANCE : st.pop();
             }
         }
 
