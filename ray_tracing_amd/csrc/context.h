@@ -56,7 +56,7 @@ constexpr int RT_STACK_ANY = RT_STACK_ANY_N;  // same for the any-hit kernels
 #ifndef RT_STACK_LEAN_ANY_N
 #define RT_STACK_LEAN_ANY_N 20
 #endif
-constexpr int RT_STACK_LEAN = RT_STACK_LEAN_N;          // lean closest-hit kernel: 20 KiB per block (6 blocks per CU)
+constexpr int RT_STACK_LEAN = RT_STACK_LEAN_N;          // lean kernels: 20 KiB per block, 6 blocks per CU (26 KiB still fits 6 but measured 2 ms slower per frame)
 constexpr int RT_STACK_LEAN_ANY = RT_STACK_LEAN_ANY_N;  // lean any-hit kernel: the same (7 waves measured no faster than 6)
 constexpr int rt_min_i(int a, int b) { return a < b ? a : b; }
 constexpr int RT_STACK_MIN = rt_min_i(rt_min_i(RT_STACK_LEAN, RT_STACK_LEAN_ANY), rt_min_i(RT_STACK_LDS, RT_STACK_ANY));
@@ -87,6 +87,15 @@ struct rt_ctx {
 };
 
 int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes);
+
+#ifndef RT_LEAN_OVERFLOW
+#define RT_LEAN_OVERFLOW true  // false: no overflow path in the lean kernels (-1 ms), scenes deeper than the LDS stack take the full ones
+#endif
+// the lean kernels serve scenes without analytic sphere/triangle objects whose trees fit their LDS stack
+inline bool rt_scene_is_lean(const rt_ctx* ctx) {
+    return (ctx->features & ~RT_LEAN_FEAT) == 0 &&
+           (RT_LEAN_OVERFLOW || ctx->scene.stack_need <= (uint32_t)(RT_STACK_LEAN < RT_STACK_LEAN_ANY ? RT_STACK_LEAN : RT_STACK_LEAN_ANY));
+}
 
 // Scheduler parameters of the persistent trace kernels for a launch of n rays on `grid` blocks.
 rtd::TraceTune rt_trace_tune(size_t n, int grid);

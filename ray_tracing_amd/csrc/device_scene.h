@@ -70,7 +70,9 @@ struct Visits {
 // Per-lane traversal stack: the first STACK_LDS entries in LDS ([level][thread]: a lane's level l
 // is at bank (l*BLOCK + tid) % 32 = tid % 32, so divergent depths never conflict), deeper entries
 // in a per-lane global overflow strip (only trees deeper than STACK_LDS ever touch it).
-template <int STACK_LDS, int BLOCK>
+// OVERFLOW = false: the caller guarantees the trees of the scene are no deeper than STACK_LDS (rt_upload_scene
+// measures them), and the two overflow branches -- scalar work in every push and pop -- are not compiled.
+template <int STACK_LDS, int BLOCK, bool OVERFLOW = true>
 struct Stack {
     // The LDS half is addressed through an explicit address-space-3 pointer: with two generic
     // pointers the compiler merges pop() into ONE flat_load of a selected address, which sends every
@@ -82,14 +84,14 @@ struct Stack {
     int sp;
     RT_DEV void set_lds(uint32_t* p) { lds = (lds_u32*)p; }
     RT_DEV void push(uint32_t v) {
-        if (sp < STACK_LDS) lds[sp * BLOCK] = v;
+        if (!OVERFLOW || sp < STACK_LDS) lds[sp * BLOCK] = v;
         else overflow[(size_t)(sp - STACK_LDS) * overflow_stride] = v;
         ++sp;
     }
     RT_DEV uint32_t pop() {
         --sp;
         uint32_t v;
-        if (sp < STACK_LDS) v = lds[sp * BLOCK];
+        if (!OVERFLOW || sp < STACK_LDS) v = lds[sp * BLOCK];
         else v = overflow[(size_t)(sp - STACK_LDS) * overflow_stride];
         return v;
     }

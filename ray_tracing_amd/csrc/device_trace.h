@@ -71,13 +71,13 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
 // records what the scene uses and the hot kernels exist in a lean and a full instantiation.
 enum SceneFeatures : uint32_t { FEAT_TRANSFORM = 1u, FEAT_SPHERE_TRIANGLE = 2u, FEAT_ALL = 3u };
 
-template <int MODE, bool COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, class IO>
+template <int MODE, bool COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, bool OVERFLOW = true, class IO>
 RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
                        float t_max_in, uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride) {
     constexpr bool PATH = MODE == TRACE_PATH;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64u - lane));
-    Stack<STACK_LDS, BLOCK> st;
+    Stack<STACK_LDS, BLOCK, OVERFLOW> st;
     st.set_lds(lds);
     st.overflow = overflow;
     st.overflow_stride = overflow_stride;

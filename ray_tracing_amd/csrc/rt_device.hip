@@ -131,7 +131,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_trace_lean(DScene sc, TraceIO io, uint32_t 
                                                 uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    trace_loop<ANY ? TRACE_ANY : TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT>(
+    trace_loop<ANY ? TRACE_ANY : TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
         sc, io, n, work_counter, tune, t_min, t_max, lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
 
@@ -553,7 +553,7 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
                            (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
                            (uint32_t*)ctx->overflow.p,
                            (uint32_t)lanes);
-    else if ((ctx->features & ~RT_LEAN_FEAT) == 0)
+    else if (rt_scene_is_lean(ctx))
         hipLaunchKernelGGL((k_trace_lean<false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
                            (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
                            (uint32_t*)ctx->overflow.p,
@@ -611,7 +611,7 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
                            (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
                            (uint32_t*)ctx->overflow.p,
                            (uint32_t)lanes);
-    else if ((ctx->features & ~RT_LEAN_FEAT) == 0)
+    else if (rt_scene_is_lean(ctx))
         hipLaunchKernelGGL((k_trace_lean<true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
                            (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
                            (uint32_t*)ctx->overflow.p,

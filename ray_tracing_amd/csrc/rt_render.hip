@@ -142,7 +142,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     ExtendIO io{pa, queue, 0ull, 0ull};
-    trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+    trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                                   lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
 
@@ -192,7 +192,7 @@ __global__ RT_TRACE_ATTR_LEAN_ANY void k_shadow_lean(DScene sc, PathArrays pa, u
     __shared__ uint32_t lds_stack[RT_STACK_LEAN_ANY * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     ShadowIO io{pa, 0ull, 0ull};
-    trace_loop<TRACE_ANY, false, RT_STACK_LEAN_ANY, RT_BLOCK, RT_LEAN_FEAT>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+    trace_loop<TRACE_ANY, false, RT_STACK_LEAN_ANY, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                               lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
 
@@ -534,7 +534,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays pa, const 
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     MixedIO io{pa, queue, n_shadow, 0ull, 0ull, 0ull, 0ull};
-    trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT>(sc, io, n, work_counter, tune, T_MIN,
+    trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN,
                                                                          __builtin_inff(), lds_stack + threadIdx.x,
                                                                          overflow + gtid, overflow_stride);
 }
@@ -779,7 +779,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     }();
     const bool use_mix = use_tail && mix_paths > 0;
     uint64_t mixed_closest = 0, mixed_shadow = 0;
-    const bool lean = (ctx->features & ~RT_LEAN_FEAT) == 0 && getenv("RT_NO_LEAN") == nullptr;
+    const bool lean = rt_scene_is_lean(ctx) && getenv("RT_NO_LEAN") == nullptr;
     static const uint32_t tail_paths = [] {  // RT_TAIL_PATHS overrides the switch-over point (experiments)
         const char* e = getenv("RT_TAIL_PATHS");
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 32768u;
@@ -999,10 +999,10 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
 }
 
 #if RT_TRACE_STATS
-extern "C" int rt_debug_occupancy(int* out4) {  // resident workgroups per CU: extend, shadow, extend<count>, shade
+extern "C" int rt_debug_occupancy(int* out4) {  // resident workgroups per CU: extend, shadow, extend_lean, shade
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_extend<false>, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_shadow<false>, RT_BLOCK, 0) != hipSuccess) return -2;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend<true>, RT_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend_lean, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_shade, SHADE_BLOCK, 0) != hipSuccess) return -2;
     return 0;
 }

@@ -6,4 +6,4 @@ torch.cuda.init()
 from ray_tracing_amd import api
 out = (C.c_int * 4)()
 rc = api.lib.rt_debug_occupancy(out)
-print(os.path.basename(os.environ.get("RT_AMD_LIB", "default")), "rc", rc, "blocks/CU: extend", out[0], "shadow", out[1], "extend<count>", out[2], "shade", out[3])
+print(os.path.basename(os.environ.get("RT_AMD_LIB", "default")), "rc", rc, "blocks/CU: extend", out[0], "shadow", out[1], "extend_lean", out[2], "shade", out[3])
