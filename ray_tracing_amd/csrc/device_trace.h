@@ -133,9 +133,9 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         bool refilled = false;  // wave-uniform: lanes received new rays in this iteration
         if (more) {
             const bool idle = ray == RAY_NONE;
-            const unsigned long long m = __ballot(idle);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(idle);
             const uint32_t n_idle = (uint32_t)__popcll(m);
-            if (n_idle >= refill_min || (n_idle > 0 && __ballot(!idle) == 0ull)) {
+            if (n_idle >= refill_min || (n_idle > 0 && __builtin_amdgcn_ballot_w64(!idle) == 0ull)) {
                 // A wave draws `chunk` consecutive rays at a time from the counter of its current
                 // segment (home segment = block index mod n_seg; the next one when that is drained).
                 // One counter for the whole launch was the bottleneck of the first version: device-
@@ -177,9 +177,9 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         const bool isdone = PATH && ray != RAY_NONE && cur == REF_DONE;
         const bool isnode = ray != RAY_NONE && (cur & LEAF_BIT) == 0u;
         const bool isleaf = ray != RAY_NONE && (cur & LEAF_BIT) != 0u && cur < REF_DONE;
-        const uint32_t n_adv = (uint32_t)__popcll(__ballot(adv)), n_node = (uint32_t)__popcll(__ballot(isnode)),
-                       n_leaf = (uint32_t)__popcll(__ballot(isleaf));
-        const uint32_t n_done = PATH ? (uint32_t)__popcll(__ballot(isdone)) : 0u;
+        const uint32_t n_adv = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(adv)), n_node = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(isnode)),
+                       n_leaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(isleaf));
+        const uint32_t n_done = PATH ? (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(isdone)) : 0u;
         if ((n_adv | n_node | n_leaf | n_done) == 0u) break;
         const uint32_t s_adv = n_adv * tune.w_adv, s_node = n_node * tune.w_node, s_leaf = n_leaf * tune.w_leaf;
         // TRACE_PATH: continuations go first once a fifth of the busy lanes wait for one (running every
@@ -248,7 +248,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             bool pending = adv;
             if (adv) fresh = false;
             for (;;) {
-                const unsigned long long pm = __ballot(pending);
+                const unsigned long long pm = __builtin_amdgcn_ballot_w64(pending);
                 if (pm == 0ull) break;
                 const uint32_t first = (uint32_t)__builtin_ctzll(pm);
                 const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)next, (int)first);
