@@ -61,6 +61,9 @@ struct RenderParams {
     uint32_t depth;
     uint32_t k0, k1;        // Philox key = seed
     uint32_t bounce;        // k_shade: RNG bounce index of this wavefront iteration (= iteration + 1)
+    uint32_t implicit_first;  // the first bounce's origin, throughput, depth and medium are the same for every
+                              // path (camera origin, 1, rp.depth, initial medium): k_generate does not store
+                              // them and the first extend / shade do not load them (64 B per path less traffic)
 };
 RT_DEV float pack_medium(int medium, bool prev_specular) {
     return __uint_as_float(((uint32_t)medium << 1) | (prev_specular ? 1u : 0u));
@@ -80,9 +83,11 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
     V3 dir = ld3(sc.camera.lower_left_corner) + u * ld3(sc.camera.horizontal) + v * ld3(sc.camera.vertical) - origin;
     dir = normalise(dir);  // camera.rs:60-63
     // :139-148: beta = 1, radiance = 0, prev_pdf = 1, prev_specular = true, current medium = initial
-    pa.ray_o[slot] = make_float4(origin.x, origin.y, origin.z, pack_medium(sc.initial_medium, true));
+    if (!rp.implicit_first) {
+        pa.ray_o[slot] = make_float4(origin.x, origin.y, origin.z, pack_medium(sc.initial_medium, true));
+        pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rp.depth));
+    }
     pa.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
-    pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rp.depth));
     pa.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     pa.queue[0][slot] = slot;
 }
@@ -103,10 +108,16 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
     PathArrays pa;
     const uint32_t* queue;
     unsigned long long n_int, n_tri;
+    const float* camera_origin;  // non-null: first bounce with implicit state (RenderParams::implicit_first)
     RT_DEV void load(uint32_t i, V3* o, V3* d) const {
         const uint32_t slot = queue[i];
-        float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
-        *o = v3(o4.x, o4.y, o4.z);
+        float4 d4 = pa.ray_d[slot];
+        if (camera_origin) {  // uniform
+            *o = v3(camera_origin[0], camera_origin[1], camera_origin[2]);
+        } else {
+            float4 o4 = pa.ray_o[slot];
+            *o = v3(o4.x, o4.y, o4.z);
+        }
         *d = v3(d4.x, d4.y, d4.z);
     }
     // a closer hit than any before it on this ray (Engine::hit's `closest = Some(..)`, :92-94)
@@ -124,24 +135,24 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
 };
 
 template <bool COUNT>
-__global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n,
+__global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n, uint32_t first,
                                                      uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                      uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    ExtendIO io{pa, queue, 0ull, 0ull};
+    ExtendIO io{pa, queue, 0ull, 0ull, first ? sc.camera.origin : nullptr};
     trace_loop<TRACE_CLOSEST, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                              lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
 }
 
 // The same kernel for scenes whose objects are meshes and planes (rtd::SceneFeatures): fewer registers, more waves.
-__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n,
+__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n, uint32_t first,
                                                  uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                  uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    ExtendIO io{pa, queue, 0ull, 0ull};
+    ExtendIO io{pa, queue, 0ull, 0ull, first ? sc.camera.origin : nullptr};
     trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                                   lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
@@ -207,7 +218,14 @@ RT_DEV float mis_weight(float pa, float pb) {  // path_integrator.rs:30-39, powe
 // One iteration of the loop body of ray_colour for the path in `slot`.  Returns QF_* flags.
 RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot,
                            uint32_t bounce) {
-    float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot], b4 = pa.beta[slot];
+    float4 d4 = pa.ray_d[slot], o4, b4;
+    if (rp.implicit_first) {  // uniform: the state k_generate left implicit (:139-148)
+        o4 = make_float4(sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2], pack_medium(sc.initial_medium, true));
+        b4 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rp.depth));
+    } else {
+        o4 = pa.ray_o[slot];
+        b4 = pa.beta[slot];
+    }
     V3 ro = v3(o4.x, o4.y, o4.z), rd = v3(d4.x, d4.y, d4.z), beta = v3(b4.x, b4.y, b4.z);
     float prev_pdf = d4.w;
     uint32_t depth = __float_as_uint(b4.w);
@@ -836,6 +854,10 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         const uint32_t s_count = std::min(s_batch, spp_count - s0);
         const uint32_t n_paths = s_count * npix;
         rp.sample_first = spp_first + s0;
+        // first-bounce state implicit unless the tail kernel takes the batch from its first bounce (it reads
+        // every path's state from memory)
+        const bool implicit = depth > 0 && !(use_tail && n_paths <= tail_paths) && getenv("RT_NO_IMPLICIT") == nullptr;
+        rp.implicit_first = implicit ? 1u : 0u;
         if ((rc = t_begin(0)) != RT_OK) return rc;
         hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, pa, rp, n_paths);
         if ((rc = t_end(0)) != RT_OK) return rc;
@@ -855,6 +877,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             const int tgrid = (int)std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
             RT_HIP(hipMemsetAsync(pa.work, 0, 2 * rtd::WORK_U32 * 4, stream));
             rp.bounce = iter + 1;  // iteration k of `while depth > 0` draws from RNG bounce k+1 (bounce 0: camera jitter)
+            const uint32_t first_implicit = (implicit && iter == 0) ? 1u : 0u;
+            rp.implicit_first = first_implicit;
             if (use_tail && n <= tail_paths) {  // few paths left: one launch takes them to their end
                 RT_HIP(hipMemsetAsync(pa.tail + 6, 0, 8, stream));
                 if ((rc = t_begin(5)) != RT_OK) return rc;
@@ -878,13 +902,13 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             if ((rc = t_begin(1)) != RT_OK) return rc;
             if (count)
                 hipLaunchKernelGGL(k_extend<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                   pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
+                                   pa.queue[cur], n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
             else if (lean)
                 hipLaunchKernelGGL(k_extend_lean, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, pa.queue[cur],
-                                   n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
+                                   n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
             else
                 hipLaunchKernelGGL(k_extend<false>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                   pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
+                                   pa.queue[cur], n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
             if ((rc = t_end(1)) != RT_OK) return rc;
             st.rays_closest += n;
             st.launches_extend += 1;
