@@ -140,67 +140,6 @@ RT_DEV bool tri_hit(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float t_min, float t_max, f
     return ok;
 }
 
-// BoundingVolumeHierarchy::traverse_bvh (bvh.rs:243-300).  Same visiting order: a leaf's
-// primitives in `indices` order; both children box-tested with the current t_max; far child
-// pushed, near child taken next, near = child1 unless t1 > t2; popped nodes are not re-culled.
-// "Push near then pop it" is folded into continuing with the near child.
-template <bool ANY, bool COUNT, int STACK_LDS, int BLOCK>
-RT_DEV bool traverse_bvh(const DScene& sc, uint32_t root_ref, V3 o, V3 d, float t_min, float& t_max,
-                         Stack<STACK_LDS, BLOCK>& st, uint32_t* hit_tri, uint32_t* hit_front, Visits* vis) {
-    V3 inv = v3(recip(d.x), recip(d.y), recip(d.z));
-    bool have = false;
-    uint32_t cur = root_ref;
-    st.sp = 0;
-    for (;;) {
-        if (cur & LEAF_BIT) {
-            uint32_t k = cur & ~LEAF_BIT;
-            uint32_t last;
-            do {
-                const float4* tp = sc.tris + (size_t)k * 3;
-                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                if (COUNT) vis->n_tri += 1;
-                float t, det;
-                if (tri_hit(v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), o, d, t_min, t_max,
-                            &t, &det)) {
-                    *hit_tri = k;
-                    *hit_front = det > 0.0f;
-                    if (ANY) return true;
-                    t_max = t;
-                    have = true;
-                }
-                last = __float_as_uint(q1.w);
-                ++k;
-            } while (!last);
-            if (st.sp == 0) break;
-            cur = st.pop();
-        } else {
-            const DPair* pp = sc.pairs + cur;
-            const float4* raw = reinterpret_cast<const float4*>(pp);
-            float4 a0 = raw[0], a1 = raw[1], b0 = raw[2], b1 = raw[3];
-            if (COUNT) vis->n_int += 1;
-            float lo1[3] = {a0.x, a0.y, a0.z}, hi1[3] = {a0.w, a1.x, a1.y};
-            float lo2[3] = {b0.x, b0.y, b0.z}, hi2[3] = {b0.w, b1.x, b1.y};
-            uint32_t ref1 = __float_as_uint(a1.z), ref2 = __float_as_uint(b1.z);
-            float t1, t2;
-            bool h1 = aabb_hit(lo1, hi1, o, inv, t_min, t_max, &t1);
-            bool h2 = aabb_hit(lo2, hi2, o, inv, t_min, t_max, &t2);
-            if (h1 && h2) {
-                bool swap = t1 > t2;
-                st.push(swap ? ref1 : ref2);
-                cur = swap ? ref2 : ref1;
-            } else if (h1) {
-                cur = ref1;
-            } else if (h2) {
-                cur = ref2;
-            } else {
-                if (st.sp == 0) break;
-                cur = st.pop();
-            }
-        }
-    }
-    return have;
-}
-
 // Sphere::hit (primitives.rs:70-94 with make_intersection :49-66)
 RT_DEV bool sphere_hit(V3 center, float radius, V3 o, V3 d, float t_min, float t_max, float* t_out, V3* n_out,
                        uint32_t* ff_out) {
@@ -232,112 +171,6 @@ RT_DEV bool plane_hit(V3 normal, float dd, V3 o, V3 d, float t_min, float t_max,
         *t_out = t;
         *ff_out = denom > 0.0f;
         return true;
-    }
-    return false;
-}
-
-// Surface::hit of one object in OBJECT space; Nearest mode.
-template <bool COUNT, int STACK_LDS, int BLOCK>
-RT_DEV bool surface_hit(const DScene& sc, const DObject& ob, V3 o, V3 d, float t_min, float t_max,
-                        Stack<STACK_LDS, BLOCK>& st, float* t_out, V3* n_out, uint32_t* ff_out, uint32_t* prim_out,
-                        Visits* vis) {
-    switch (ob.kind) {
-        case RT_SURF_MESH: {
-            uint32_t tri = 0, ff = 0;
-            float tm = t_max;
-            if (!traverse_bvh<false, COUNT, STACK_LDS, BLOCK>(sc, ob.root_ref, o, d, t_min, tm, st, &tri, &ff, vis))
-                return false;
-            const float4* tp = sc.tris + (size_t)tri * 3;
-            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-            *t_out = tm;
-            *n_out = normalise(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));  // primitives.rs:175
-            *ff_out = ff;
-            *prim_out = __float_as_uint(q0.w);
-            return true;
-        }
-        case RT_SURF_SPHERE:
-            *prim_out = 0;
-            return sphere_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), ob.surf[3], o, d, t_min, t_max, t_out, n_out,
-                              ff_out);
-        case RT_SURF_PLANE:
-            *prim_out = 0;
-            *n_out = v3(ob.surf[0], ob.surf[1], ob.surf[2]);
-            return plane_hit(*n_out, ob.surf[3], o, d, t_min, t_max, t_out, ff_out);
-        case RT_SURF_TRIANGLE: {
-            V3 e1 = v3(ob.surf[3], ob.surf[4], ob.surf[5]), e2 = v3(ob.surf[6], ob.surf[7], ob.surf[8]);
-            float t, det;
-            if (!tri_hit(v3(ob.surf[0], ob.surf[1], ob.surf[2]), e1, e2, o, d, t_min, t_max, &t, &det)) return false;
-            *t_out = t;
-            *n_out = normalise(cross(e1, e2));
-            *ff_out = det > 0.0f;
-            *prim_out = 0;
-            return true;
-        }
-        default:
-            return false;  // Point (primitives.rs:19-23)
-    }
-}
-
-// Engine::hit (path_integrator.rs:88-97) over Object::hit (object.rs:32-68).
-template <bool COUNT, int STACK_LDS, int BLOCK>
-RT_DEV bool scene_hit(const DScene& sc, V3 o, V3 d, float t_min, float t_max, Stack<STACK_LDS, BLOCK>& st, Hit* hit,
-                      Visits* vis) {
-    bool result = false;
-    for (uint32_t i = 0; i < sc.n_objects; ++i) {
-        const DObject& ob = sc.objects[i];
-        float t;
-        V3 n;
-        uint32_t ff, prim;
-        bool h;
-        if (!ob.has_transform) {
-            h = surface_hit<COUNT, STACK_LDS, BLOCK>(sc, ob, o, d, t_min, t_max, st, &t, &n, &ff, &prim, vis);
-        } else {
-            V3 oo = mat_mul(ob.inv_m, o) + v3(ob.inv_t[0], ob.inv_t[1], ob.inv_t[2]);
-            V3 dd = mat_mul(ob.inv_m, d);
-            float nr = norm_recip(dd);
-            h = surface_hit<COUNT, STACK_LDS, BLOCK>(sc, ob, oo, dd * nr, t_min, t_max, st, &t, &n, &ff, &prim, vis);
-            if (h) {
-                t = t * nr;
-                n = normalise(mat_transpose_mul(ob.inv_m, n));
-            }
-        }
-        if (h) {
-            t_max = t;
-            hit->t = t;
-            hit->normal = n;
-            hit->front_face = ff;
-            hit->prim = prim;
-            hit->obj = i;
-            result = true;
-        }
-    }
-    return result;
-}
-
-// Engine::hit_bool (path_integrator.rs:100-104) over Object::hit_bool (object.rs:71-87).
-template <bool COUNT, int STACK_LDS, int BLOCK>
-RT_DEV bool scene_hit_bool(const DScene& sc, V3 o, V3 d, float t_min, float t_max, Stack<STACK_LDS, BLOCK>& st,
-                           Visits* vis) {
-    for (uint32_t i = 0; i < sc.n_objects; ++i) {
-        const DObject& ob = sc.objects[i];
-        V3 oo = o, dd = d;
-        if (ob.has_transform) {
-            oo = mat_mul(ob.inv_m, o) + v3(ob.inv_t[0], ob.inv_t[1], ob.inv_t[2]);
-            dd = mat_mul(ob.inv_m, d);
-            dd = dd * norm_recip(dd);
-        }
-        bool h;
-        if (ob.kind == RT_SURF_MESH) {
-            uint32_t tri, ff;
-            float tm = t_max;
-            h = traverse_bvh<true, COUNT, STACK_LDS, BLOCK>(sc, ob.root_ref, oo, dd, t_min, tm, st, &tri, &ff, vis);
-        } else {
-            float t;
-            V3 n;
-            uint32_t ff, prim;
-            h = surface_hit<COUNT, STACK_LDS, BLOCK>(sc, ob, oo, dd, t_min, t_max, st, &t, &n, &ff, &prim, vis);
-        }
-        if (h) return true;
     }
     return false;
 }
