@@ -55,14 +55,6 @@ struct DScene {
     uint32_t tri_off;     // byte offset of tris from pairs (one allocation, < 4 GiB, 64 B of slack after it)
 };
 
-struct Hit {  // SurfaceIntersection (traits.rs:13-17) + ids
-    float t;
-    V3 normal;
-    uint32_t front_face;
-    uint32_t prim;  // original triangle index in its mesh
-    uint32_t obj;
-};
-
 struct Visits {
     uint32_t n_int, n_tri;
 };
