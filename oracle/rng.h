@@ -8,8 +8,10 @@
 //
 //   Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11)
 //   key     = (seed low 32, seed high 32)
-//   counter = (pixel = j*width+i, global sample index, bounce, draw index within the bounce)
-//   value   = output word 0
+//   counter = (pixel = j*width+i, global sample index, bounce, block index within the bounce)
+//   value   = draw d of a bounce is output word d % 4 of block d / 4 (all four words of a block are used:
+//             the block function is the expensive part of shading on the device -- 40 quarter-rate
+//             integer multiplies -- and a bounce makes about seven draws)
 //
 // bounce 0 holds the two camera-jitter draws of Engine::render (path_integrator.rs:303-304);
 // iteration k >= 1 of the `while depth > 0` loop of ray_colour (:150) is bounce k.
@@ -41,13 +43,20 @@ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 struct Rng {
     uint32_t key[2];
     uint32_t pixel, sample, bounce, dim;
+    uint32_t block[4], have;  // cached block and its index (0xFFFFFFFF: none)
     Rng(uint64_t seed, uint32_t pixel_, uint32_t sample_)
-        : key{(uint32_t)seed, (uint32_t)(seed >> 32)}, pixel(pixel_), sample(sample_), bounce(0), dim(0) {}
-    void set_bounce(uint32_t b) { bounce = b; dim = 0; }
+        : key{(uint32_t)seed, (uint32_t)(seed >> 32)}, pixel(pixel_), sample(sample_), bounce(0), dim(0),
+          block{0, 0, 0, 0}, have(0xFFFFFFFFu) {}
+    void set_bounce(uint32_t b) { bounce = b; dim = 0; have = 0xFFFFFFFFu; }
     uint32_t u32() {
-        uint32_t ctr[4] = {pixel, sample, bounce, dim++}, out[4];
-        philox4x32_10(ctr, key, out);
-        return out[0];
+        const uint32_t b = dim >> 2, w = dim & 3u;
+        if (have != b) {
+            uint32_t ctr[4] = {pixel, sample, bounce, b};
+            philox4x32_10(ctr, key, block);
+            have = b;
+        }
+        ++dim;
+        return block[w];
     }
     float f32() { return (float)(u32() >> 9) * 1.1920928955078125e-7f; }
     uint32_t usize(uint32_t n) { return (uint32_t)(((uint64_t)u32() * n) >> 32); }

@@ -176,9 +176,10 @@ RT_DEV float logf_(float yf) {
 }
 
 // ---------------------------------------------------------------- counter-based RNG
-// Philox4x32-10; key = 64-bit seed, counter = (pixel, global sample, bounce, draw); word 0 is used.
-// Replaces the single sequential fastrand::Rng of the reference (path_integrator.rs:286).
-RT_DEV uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+// Philox4x32-10; key = 64-bit seed, counter = (pixel, global sample, bounce, block); draw d of a bounce is
+// word d % 4 of block d / 4 (oracle/rng.h).  Replaces the single sequential fastrand::Rng of the
+// reference (path_integrator.rs:286).
+RT_DEV void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -190,12 +191,18 @@ RT_DEV uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
         k0 += W0;
         k1 += W1;
     }
-    return c0;
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-struct Rng {
+struct Rng {  // used from draw 0 of a bounce onwards, in order
     uint32_t k0, k1, pixel, sample, bounce, dim;
-    RT_DEV uint32_t u32() { return philox_word0(pixel, sample, bounce, dim++, k0, k1); }
+    uint32_t w[4];
+    RT_DEV uint32_t u32() {
+        const uint32_t i = dim & 3u;
+        if (i == 0u) philox_block(pixel, sample, bounce, dim >> 2, k0, k1, w);
+        ++dim;
+        return i == 0u ? w[0] : i == 1u ? w[1] : i == 2u ? w[2] : w[3];
+    }
     RT_DEV float f32() { return (float)(u32() >> 9) * 1.1920928955078125e-7f; }  // [0,1) on 2^-23
     RT_DEV uint32_t usize(uint32_t n) { return __umulhi(u32(), n); }              // rng.usize(0..n)
 };
