@@ -301,7 +301,7 @@ typedef struct rt_stats {
    ray_colour (:138-276) of samples [spp_first, spp_first+spp_count) IN SAMPLE ORDER and stores the
    sum in rgb_sum[(j*width+i)*3 .. +3] (j = the reference's v index, row 0 = bottom).  rgb_sum may
    be host or device memory.  Random numbers: Philox4x32-10 keyed by seed, counter
-   (pixel=j*width+i, global sample index, bounce, draw) -- see DESIGN.md.  stats may be NULL. */
+   (pixel=j*width+i, global sample index, bounce, draw/4), word draw%4 -- see DESIGN.md.  stats may be NULL. */
 int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp_first, uint32_t spp_count,
               uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats);
 
