@@ -103,6 +103,12 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     Visits vis = {0, 0};
 #if RT_TRACE_STATS
     unsigned long long s_stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long s_cyc[5] = {0, 0, 0, 0, 0};  // wave cycles in: scheduler+refill, advance, node, leaf, (total)
+    unsigned long long t_mark = __builtin_readcyclecounter();
+    const unsigned long long t_start = t_mark;
+#define RT_CYC(i) { unsigned long long t_now = __builtin_readcyclecounter(); s_cyc[i] += t_now - t_mark; t_mark = t_now; }
+#else
+#define RT_CYC(i)
 #endif
 
     // a ray is finished: hand it to the IO policy now, or (TRACE_PATH) park the lane for phase D
@@ -207,6 +213,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         }
 #endif
 
+        RT_CYC(0)
         // ---------------------------------------------------------------- D: continuation (TRACE_PATH)
         if constexpr (PATH) {
             if (run_done && isdone) {
@@ -331,6 +338,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             }
         }
 
+        RT_CYC(1)
         // ---------------------------------------------------------------- B: internal node
 #ifndef RT_NODE_REPS
 #define RT_NODE_REPS 3
@@ -361,6 +369,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             }
         }
 
+        RT_CYC(2)
         // ---------------------------------------------------------------- C: leaf
         if (run_leaf) {
             if (isleaf) {
@@ -389,10 +398,14 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                 if (!done) cur = st.sp == 0 ? REF_ADVANCE : st.pop();
             }
         }
+        RT_CYC(3)
     }
 #if RT_TRACE_STATS
-    if (lane == 0)
+    if (lane == 0) {
         for (int i = 0; i < 8; ++i) atomicAdd(&g_trace_stats[(MODE == TRACE_ANY ? 8 : 0) + i], s_stat[i]);
+        s_cyc[4] = __builtin_readcyclecounter() - t_start;
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_trace_stats[(MODE == TRACE_ANY ? 24 : 16) + i], s_cyc[i]);
+    }
 #endif
 }
 

@@ -21,3 +21,7 @@ for name, o in (("extend", 0), ("shadow", 8)):
     tot = it * 64
     print(f"{name}: iterations {it}  advance {run/tot:.3f}  wait-phase {wait/tot:.3f}  idle(queue) {idle_more/tot:.3f}  idle(drain) {idle_drain/tot:.3f}"
           f"  phases node {pn/it:.3f} leaf {pl/it:.3f} adv {pa/it:.3f}  lanes/iter {run/it:.1f}")
+    c = [buf[16 + o + i] for i in range(5)]
+    if c[4]:
+        print(f"   wave cycles: scheduler+refill {c[0]/c[4]:.3f}  advance {c[1]/c[4]:.3f}  node {c[2]/c[4]:.3f}  leaf {c[3]/c[4]:.3f}"
+              f"   per iteration: {c[4]/it:.0f} cycles (sched {c[0]/it:.0f}, adv {c[1]/max(1,pa):.0f} per adv phase, node {c[2]/max(1,pn):.0f} per node phase, leaf {c[3]/max(1,pl):.0f} per leaf phase)")
