@@ -57,7 +57,9 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
 }
 
 // IO policy (one object per lane):
-//   load(i, &o, &d)                        world-space ray i of the launch
+//   load(i, &o, &d) -> tag                 world-space ray i of the launch; the tag (never 0xFFFFFFFF) names
+//                                          the ray in every later call -- `i` below -- so that a policy whose
+//                                          rays sit behind a queue looks its slot up once
 //   hit(i, t, n, meta, prim)               closest-hit rays: a hit closer than any before it on ray i
 //   emit_closest(i, got, vis)              closest-hit ray i is finished
 //   emit_any(i, occluded, vis)             any-hit ray i is finished
@@ -98,6 +100,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     bool got = false;                                 // a hit has been recorded through io.hit()
     uint32_t hit_tri = 0;
     bool hit_ff = false, obj_hit = false, fresh = false;
+    uint32_t cand = 0xFFFFFFFFu;                      // objects (of the first 32) this ray can hit at all
     bool lane_any = MODE == TRACE_ANY;                // TRACE_PATH: kind of this lane's current ray
     bool done_occluded = false;                       // TRACE_PATH: outcome of a finished any-hit ray
     Visits vis = {0, 0};
@@ -130,6 +133,25 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         fresh = true;
         st.sp = 0;
         if (COUNT) vis = {0, 0};
+        // Top level: one slab test per bounded object against the WORLD ray, before any per-object transform.
+        // Objects whose bounds the ray misses drop out of Engine::hit's loop for this ray; the others are
+        // still met in vector order with the reference's shrinking t_max.  Not when counting visits.
+        if (!COUNT && sc.cull_test != 0u) {  // uniform
+            const V3 winv = v3(recip(wd.x), recip(wd.y), recip(wd.z));
+            cand = ~sc.cull_test;
+            for (uint32_t m = sc.cull_test; m != 0u; m &= m - 1u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(m);
+                const float* b = sc.wbox + 8u * k;
+                float t_entry;
+                if (aabb_hit(b, b + 3, wo, winv, t_min, t_max_in, &t_entry)) cand |= 1u << k;
+            }
+        }
+    };
+    // the first object >= from that the ray can hit (objects past the 32nd are always candidates)
+    auto next_cand = [&](uint32_t from) -> uint32_t {
+        if (COUNT) return from;
+        const uint32_t rem = from < 32u ? cand & (0xFFFFFFFFu << from) : 0u;
+        return rem != 0u ? (uint32_t)__builtin_ctz(rem) : max(from, 32u);
     };
 
     for (;;) {
@@ -164,9 +186,9 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     const uint32_t take = min(n_idle, pool_end - pool_next);
                     const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
                     if (idle && rank < take) {
-                        ray = pool_next + rank;
-                        io.load(ray, &wo, &wd);
-                        if constexpr (PATH) lane_any = io.first_is_any(ray);
+                        const uint32_t idx = pool_next + rank;
+                        ray = io.load(idx, &wo, &wd);
+                        if constexpr (PATH) lane_any = io.first_is_any(idx);
                         begin_ray();
                     }
                     pool_next += take;
@@ -232,6 +254,15 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         if (run_adv) {
             if (adv) {
                 if (obj_hit) {  // close the mesh traversal that just ended (Object::hit tail, object.rs:56-65)
+                  if constexpr (IO::DEFER_NORMAL) {
+                    // The consumer rebuilds the normal from the triangle (hit_mesh's `tri`), with the same
+                    // arithmetic: no dependent triangle fetch stalls the wave here.  nr is 1 for an object
+                    // without a transform, and t * 1 is t.
+                    const float t = (FEAT & FEAT_TRANSFORM) ? tmax * nr : tmax;
+                    best_t = t;
+                    got = true;
+                    io.hit_mesh(ray, t, obj | (hit_ff ? 0x80000000u : 0u), hit_tri);
+                  } else {
                     const DObject& ob = sc.objects[obj];
                     float4 q0 = ld16(sc.tris, hit_tri * 48u), q1 = ld16(sc.tris, hit_tri * 48u + 16u),
                            q2 = ld16(sc.tris, hit_tri * 48u + 32u);
@@ -244,6 +275,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     best_t = t;
                     got = true;
                     io.hit(ray, t, nrm, obj | (hit_ff ? 0x80000000u : 0u), __float_as_uint(q0.w));
+                  }
                     obj_hit = false;
                 }
             }
@@ -251,7 +283,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             // the next object index k of its first waiting lane and serves every lane waiting for that
             // same k, so the object record is read through a uniform address (scalar registers) instead
             // of one copy per lane -- a lane still meets the objects in vector order.
-            uint32_t next = fresh ? 0u : obj + 1u;
+            uint32_t next = next_cand(fresh ? 0u : obj + 1u);
             bool pending = adv;
             if (adv) fresh = false;
             for (;;) {
@@ -270,9 +302,10 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                 const DObject& ob = sc.objects[k];
                 if (mine) {
                     obj = k;
-                    next = k + 1u;
+                    next = next_cand(k + 1u);
                     o = wo;
                     d = wd;
+                    nr = 1.0f;
                     if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {  // object.rs:39-45
                         o = mat_mul(ob.inv_m, wo) + v3(ob.inv_t[0], ob.inv_t[1], ob.inv_t[2]);
                         d = mat_mul(ob.inv_m, wd);

@@ -78,11 +78,13 @@ struct TraceIO {  // caller-provided SoA ray batch and hit arrays (rt_rays / rt_
     rt_rays rays;
     rt_hits out;
     uint8_t* occluded;
-    RT_DEV void load(uint32_t i, V3* o, V3* d) const {
+    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {
         *o = v3(rays.ox[i], rays.oy[i], rays.oz[i]);
         *d = v3(rays.dx[i], rays.dy[i], rays.dz[i]);
+        return i;
     }
     // a closer hit than any before it on this ray (Engine::hit's `closest = Some(..)`, :92-94)
+    static constexpr bool DEFER_NORMAL = false;  // callers get the normal and the primitive id
     RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
         out.t[i] = t;
         if (out.prim) out.prim[i] = prim;
@@ -251,7 +253,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->pairs, &ctx->tris, &ctx->objects, &ctx->materials, &ctx->lights, &ctx->media,
+    DevBuf* bufs[] = {&ctx->pairs, &ctx->tris, &ctx->objects, &ctx->materials, &ctx->lights, &ctx->media, &ctx->wbox,
                       &ctx->overflow, &ctx->path_state, &ctx->queues, &ctx->counters, &ctx->sample_sum};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->staging) b.release();
@@ -412,6 +414,53 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
         o.medium_inside = f.medium_inside;
         o.medium_outside = f.medium_outside;
     }
+    // ---- top level over objects (DScene::wbox): world-space bounds of every mesh among the first 32 objects.
+    // Without a transform, and with an internal root, the bounds are the root box itself and the test is the
+    // one the object loop would make (exact, see device_trace.h).  Otherwise the box is the hull of the 8
+    // root-box corners taken to world space in f64, widened by 1e-4 of the scene scale: a hit the reference
+    // finds lies within a few f32 roundings (1e-7 relative) of a triangle, all triangles lie inside the root
+    // box, so its ray passes the widened box with a margin three orders above every rounding on the way.
+    std::vector<float> wbox(8 * 32, 0.0f);
+    uint32_t cull_test = 0;
+    for (uint32_t i = 0; i < s->n_objects && i < 32u; ++i) {
+        const DObject& o = objs[i];
+        if (o.kind != RT_SURF_MESH) continue;
+        double lo[3], hi[3];
+        bool ok = true;
+        if (!o.has_transform && (o.root_ref & rtd::LEAF_BIT) == 0u) {
+            for (int a = 0; a < 3; ++a) lo[a] = o.surf[a], hi[a] = o.surf[3 + a];
+        } else {
+            double m[9], inv[9];  // forward matrix = inverse of the stored inverse; identity without a transform
+            for (int a = 0; a < 9; ++a) m[a] = o.has_transform ? (double)o.inv_m[a] : (a % 4 == 0 ? 1.0 : 0.0);
+            const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+                               m[2] * (m[3] * m[7] - m[4] * m[6]);
+            if (!(std::fabs(det) > 1e-30)) continue;
+            inv[0] = (m[4] * m[8] - m[5] * m[7]) / det, inv[1] = (m[2] * m[7] - m[1] * m[8]) / det, inv[2] = (m[1] * m[5] - m[2] * m[4]) / det;
+            inv[3] = (m[5] * m[6] - m[3] * m[8]) / det, inv[4] = (m[0] * m[8] - m[2] * m[6]) / det, inv[5] = (m[2] * m[3] - m[0] * m[5]) / det;
+            inv[6] = (m[3] * m[7] - m[4] * m[6]) / det, inv[7] = (m[1] * m[6] - m[0] * m[7]) / det, inv[8] = (m[0] * m[4] - m[1] * m[3]) / det;
+            for (int a = 0; a < 3; ++a) lo[a] = 1e300, hi[a] = -1e300;
+            for (int c = 0; c < 8; ++c) {
+                double x[3];
+                for (int a = 0; a < 3; ++a)
+                    x[a] = (double)((c >> a) & 1 ? o.surf[3 + a] : o.surf[a]) - (o.has_transform ? (double)o.inv_t[a] : 0.0);
+                for (int a = 0; a < 3; ++a) {
+                    const double w = inv[3 * a] * x[0] + inv[3 * a + 1] * x[1] + inv[3 * a + 2] * x[2];
+                    lo[a] = std::min(lo[a], w), hi[a] = std::max(hi[a], w);
+                }
+            }
+            double scale = 0.0;
+            for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::max(std::fabs(lo[a]), std::fabs(hi[a])), hi[a] - lo[a]));
+            const double pad = 1e-4 * scale + 1e-30;
+            for (int a = 0; a < 3; ++a) lo[a] -= pad, hi[a] += pad;
+        }
+        for (int a = 0; a < 3; ++a) {
+            const float l = (float)lo[a], h = (float)hi[a];
+            if (!std::isfinite(l) || !std::isfinite(h) || !(l <= h)) ok = false;
+            wbox[8 * i + a] = (double)l <= lo[a] ? l : std::nextafterf(l, -INFINITY);
+            wbox[8 * i + 3 + a] = (double)h >= hi[a] ? h : std::nextafterf(h, INFINITY);
+        }
+        if (ok) cull_test |= 1u << i;
+    }
     if (s->initial_medium >= (int32_t)s->n_media || s->initial_medium < RT_MEDIUM_AUTO) {
         rth::set_error("rt_upload_scene: initial_medium out of range");
         return RT_ERR_INVALID;
@@ -439,6 +488,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
     if (tri_bytes)
         RT_HIP(hipMemcpyAsync((char*)ctx->pairs.p + tri_off, tris.data(), tri_bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = up(ctx->objects, objs.data(), objs.size() * sizeof(DObject))) != RT_OK) return rc;
+    if ((rc = up(ctx->wbox, wbox.data(), wbox.size() * sizeof(float))) != RT_OK) return rc;
     if ((rc = up(ctx->materials, s->materials, s->n_materials * sizeof(rt_material))) != RT_OK) return rc;
     if ((rc = up(ctx->lights, s->lights, s->n_lights * sizeof(rt_light))) != RT_OK) return rc;
     if ((rc = up(ctx->media, s->media, s->n_media * sizeof(rt_medium))) != RT_OK) return rc;
@@ -459,6 +509,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
     d.camera = s->camera;
     d.initial_medium = s->initial_medium == RT_MEDIUM_AUTO ? RT_MEDIUM_NONE : s->initial_medium;
     d.stack_need = stack_need;
+    d.wbox = (const float*)ctx->wbox.p;
+    d.cull_test = cull_test;
     ctx->overflow_levels = stack_need > (uint32_t)RT_STACK_MIN ? stack_need - RT_STACK_MIN : 0;
     ctx->features = features;
     ctx->has_scene = true;

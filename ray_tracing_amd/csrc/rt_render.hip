@@ -38,8 +38,8 @@ struct PathArrays {      // SoA over slots
     float4* ray_d;       // direction.xyz, prev_pdf
     float4* beta;        // throughput.xyz, bits: depth (u32; wraps like the reference's, path_integrator.rs:193)
     float4* rad;         // radiance.xyz, -
-    float4* hit_a;       // t, normal.xyz
-    uint2* hit_b;        // obj | front_face<<31 (RT_MISS = no hit), prim
+    float4* hit_a;       // t, normal.xyz (normal of analytic surfaces only)
+    uint2* hit_b;        // obj | front_face<<31 (RT_MISS = no hit), triangle slot of a mesh hit (normal: shade_path)
     float4* sh_d;        // shadow direction.xyz, - (the shadow ray starts at ray_o: the vertex just shaded)
     float4* sh_c;        // pending NEE term.xyz, apply flag
     uint32_t* queue[2];  // live-path queues (ping-pong)
@@ -109,7 +109,7 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
     const uint32_t* queue;
     unsigned long long n_int, n_tri;
     const float* camera_origin;  // non-null: first bounce with implicit state (RenderParams::implicit_first)
-    RT_DEV void load(uint32_t i, V3* o, V3* d) const {
+    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // returns the path's slot: the ray's tag from here on
         const uint32_t slot = queue[i];
         float4 d4 = pa.ray_d[slot];
         if (camera_origin) {  // uniform
@@ -119,15 +119,21 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
             *o = v3(o4.x, o4.y, o4.z);
         }
         *d = v3(d4.x, d4.y, d4.z);
+        return slot;
     }
     // a closer hit than any before it on this ray (Engine::hit's `closest = Some(..)`, :92-94)
-    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
-        const uint32_t slot = queue[i];
+    RT_DEV void hit(uint32_t slot, float t, V3 n, uint32_t meta, uint32_t prim) const {
         pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
         pa.hit_b[slot] = make_uint2(meta, prim);
     }
-    RT_DEV void emit_closest(uint32_t i, bool got, const Visits& vis) {
-        if (!got) pa.hit_b[queue[i]] = make_uint2(RT_MISS, RT_MISS);
+    // a closer hit on a mesh: the normal is left to shade_path, which rebuilds it from triangle `tri`
+    static constexpr bool DEFER_NORMAL = true;
+    RT_DEV void hit_mesh(uint32_t slot, float t, uint32_t meta, uint32_t tri) const {
+        ((float*)&pa.hit_a[slot])[0] = t;
+        pa.hit_b[slot] = make_uint2(meta, tri);
+    }
+    RT_DEV void emit_closest(uint32_t slot, bool got, const Visits& vis) {
+        if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
         n_int += vis.n_int;
         n_tri += vis.n_tri;
     }
@@ -161,17 +167,18 @@ __global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const
 struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds its pending NEE term
     PathArrays pa;
     unsigned long long n_int, n_tri;
-    RT_DEV void load(uint32_t i, V3* o, V3* d) const {
+    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {
         const uint32_t slot = pa.shadow_q[i];
         float4 o4 = pa.ray_o[slot], d4 = pa.sh_d[slot];
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
+        return slot;
     }
+    static constexpr bool DEFER_NORMAL = false;
     RT_DEV void hit(uint32_t, float, V3, uint32_t, uint32_t) const {}
     RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
-    RT_DEV void emit_any(uint32_t i, bool occluded, const Visits& vis) {
+    RT_DEV void emit_any(uint32_t slot, bool occluded, const Visits& vis) {
         if (!occluded) {
-            const uint32_t slot = pa.shadow_q[i];
             float4 c = pa.sh_c[slot];
             if (c.w != 0.0f) {  // p_light > 0 (path_integrator.rs:234)
                 float4 r = pa.rad[slot];
@@ -300,6 +307,12 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
     const DObject& ob = sc.objects[hb.x & 0x7FFFFFFFu];
     bool front_face = (hb.x >> 31) != 0;
     const rt_material& mat = sc.materials[ob.material];
+    if (ob.kind == RT_SURF_MESH) {  // hit_mesh left the normal to us: primitives.rs:175, then object.rs:60-63
+        const uint32_t tri = hb.y;
+        float4 q1 = ld16(sc.tris, tri * 48u + 16u), q2 = ld16(sc.tris, tri * 48u + 32u);
+        normal = normalise(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));
+        if (ob.has_transform) normal = normalise(mat_transpose_mul(ob.inv_m, normal));
+    }
     V3 interaction_point = ro + rd * t_hit;
     V3 wo_local = to_shading_coords(-rd, normal);
 
@@ -393,7 +406,7 @@ struct TailIO {
     unsigned long long n_int, n_tri;                   // closest-hit visits (COUNT)
     unsigned long long n_int_sh, n_tri_sh;             // shadow visits (COUNT)
     bool alive_after;                                  // the path goes on after its pending shadow ray
-    RT_DEV void load(uint32_t i, V3* o, V3* d) {
+    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) {
         const uint32_t slot = queue[i];
         float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
         *o = v3(o4.x, o4.y, o4.z);
@@ -401,10 +414,15 @@ struct TailIO {
         n_closest += 1;
         iters = 1;
         if (iters > max_iters) max_iters = iters;
+        return slot;
+    }
+    static constexpr bool DEFER_NORMAL = true;
+    RT_DEV void hit_mesh(uint32_t slot, float t, uint32_t meta, uint32_t tri) const {
+        ((float*)&pa.hit_a[slot])[0] = t;
+        pa.hit_b[slot] = make_uint2(meta, tri);
     }
     RT_DEV bool first_is_any(uint32_t) const { return false; }
-    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
-        const uint32_t slot = queue[i];
+    RT_DEV void hit(uint32_t slot, float t, V3 n, uint32_t meta, uint32_t prim) const {
         pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
         pa.hit_b[slot] = make_uint2(meta, prim);
     }
@@ -420,8 +438,7 @@ struct TailIO {
         if (iters > max_iters) max_iters = iters;
         return true;
     }
-    RT_DEV bool next(uint32_t i, bool was_any, bool got, bool occluded, const Visits& vis, V3* o, V3* d, bool* any) {
-        const uint32_t slot = queue[i];
+    RT_DEV bool next(uint32_t slot, bool was_any, bool got, bool occluded, const Visits& vis, V3* o, V3* d, bool* any) {
         if (!was_any) {
             n_int += vis.n_int;
             n_tri += vis.n_tri;
@@ -493,26 +510,30 @@ struct MixedIO {
     uint32_t n_shadow;
     unsigned long long n_int, n_tri, n_int_sh, n_tri_sh;
     RT_DEV bool first_is_any(uint32_t i) const { return i < n_shadow; }
-    RT_DEV void load(uint32_t i, V3* o, V3* d) const {
+    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {
         const bool sh = i < n_shadow;
         const uint32_t slot = sh ? pa.shadow_q[i] : queue[i - n_shadow];
         float4 o4 = pa.ray_o[slot], d4 = sh ? pa.sh_d[slot] : pa.ray_d[slot];
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
+        return slot;
     }
-    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
-        const uint32_t slot = queue[i - n_shadow];
+    static constexpr bool DEFER_NORMAL = true;
+    RT_DEV void hit_mesh(uint32_t slot, float t, uint32_t meta, uint32_t tri) const {
+        ((float*)&pa.hit_a[slot])[0] = t;
+        pa.hit_b[slot] = make_uint2(meta, tri);
+    }
+    RT_DEV void hit(uint32_t slot, float t, V3 n, uint32_t meta, uint32_t prim) const {
         pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
         pa.hit_b[slot] = make_uint2(meta, prim);
     }
     RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
     RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
-    RT_DEV bool next(uint32_t i, bool was_any, bool got, bool occluded, const Visits& vis, V3*, V3*, bool*) {
+    RT_DEV bool next(uint32_t slot, bool was_any, bool got, bool occluded, const Visits& vis, V3*, V3*, bool*) {
         if (was_any) {
             n_int_sh += vis.n_int;
             n_tri_sh += vis.n_tri;
             if (!occluded) {
-                const uint32_t slot = pa.shadow_q[i];
                 float4 c = pa.sh_c[slot];
                 if (c.w != 0.0f) {  // p_light > 0 (path_integrator.rs:234)
                     float4 r = pa.rad[slot];
@@ -525,7 +546,7 @@ struct MixedIO {
         } else {
             n_int += vis.n_int;
             n_tri += vis.n_tri;
-            if (!got) pa.hit_b[queue[i - n_shadow]] = make_uint2(RT_MISS, RT_MISS);
+            if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
         }
         return false;
     }
