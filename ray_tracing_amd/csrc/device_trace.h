@@ -100,7 +100,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     bool got = false;                                 // a hit has been recorded through io.hit()
     uint32_t hit_tri = 0;
     bool hit_ff = false, obj_hit = false, fresh = false;
-    uint32_t cand = 0xFFFFFFFFu;                      // objects (of the first 32) this ray can hit at all
+    unsigned long long cand = ~0ull;                  // objects (of the first 64) this ray can hit at all
     bool lane_any = MODE == TRACE_ANY;                // TRACE_PATH: kind of this lane's current ray
     bool done_occluded = false;                       // TRACE_PATH: outcome of a finished any-hit ray
     Visits vis = {0, 0};
@@ -136,22 +136,22 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         // Top level: one slab test per bounded object against the WORLD ray, before any per-object transform.
         // Objects whose bounds the ray misses drop out of Engine::hit's loop for this ray; the others are
         // still met in vector order with the reference's shrinking t_max.  Not when counting visits.
-        if (!COUNT && sc.cull_test != 0u) {  // uniform
+        if (!COUNT && sc.cull_test != 0ull) {  // uniform
             const V3 winv = v3(recip(wd.x), recip(wd.y), recip(wd.z));
             cand = ~sc.cull_test;
-            for (uint32_t m = sc.cull_test; m != 0u; m &= m - 1u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(m);
+            for (unsigned long long m = sc.cull_test; m != 0ull; m &= m - 1ull) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(m);
                 const float* b = sc.wbox + 8u * k;
                 float t_entry;
-                if (aabb_hit(b, b + 3, wo, winv, t_min, t_max_in, &t_entry)) cand |= 1u << k;
+                if (aabb_hit(b, b + 3, wo, winv, t_min, t_max_in, &t_entry)) cand |= 1ull << k;
             }
         }
     };
-    // the first object >= from that the ray can hit (objects past the 32nd are always candidates)
+    // the first object >= from that the ray can hit (objects past the 64th are always candidates)
     auto next_cand = [&](uint32_t from) -> uint32_t {
         if (COUNT) return from;
-        const uint32_t rem = from < 32u ? cand & (0xFFFFFFFFu << from) : 0u;
-        return rem != 0u ? (uint32_t)__builtin_ctz(rem) : max(from, 32u);
+        const unsigned long long rem = from < 64u ? cand & (~0ull << from) : 0ull;
+        return rem != 0ull ? (uint32_t)__builtin_ctzll(rem) : max(from, 64u);
     };
 
     for (;;) {

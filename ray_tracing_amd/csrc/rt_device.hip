@@ -414,21 +414,21 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
         o.medium_inside = f.medium_inside;
         o.medium_outside = f.medium_outside;
     }
-    // ---- top level over objects (DScene::wbox): world-space bounds of every mesh among the first 32 objects.
-    // Without a transform, and with an internal root, the bounds are the root box itself and the test is the
-    // one the object loop would make (exact, see device_trace.h).  Otherwise the box is the hull of the 8
+    // ---- top level over objects (DScene::wbox): world-space bounds of every mesh among the first 64 objects.
+    // Without a transform, and with an internal root, the object loop's exact root-box test (device_trace.h)
+    // already does this at the same price: no entry.  Otherwise the box is the hull of the 8
     // root-box corners taken to world space in f64, widened by 1e-4 of the scene scale: a hit the reference
     // finds lies within a few f32 roundings (1e-7 relative) of a triangle, all triangles lie inside the root
     // box, so its ray passes the widened box with a margin three orders above every rounding on the way.
-    std::vector<float> wbox(8 * 32, 0.0f);
-    uint32_t cull_test = 0;
-    for (uint32_t i = 0; i < s->n_objects && i < 32u; ++i) {
+    std::vector<float> wbox(8 * 64, 0.0f);
+    unsigned long long cull_test = 0;
+    for (uint32_t i = 0; i < s->n_objects && i < 64u; ++i) {
         const DObject& o = objs[i];
         if (o.kind != RT_SURF_MESH) continue;
         double lo[3], hi[3];
         bool ok = true;
         if (!o.has_transform && (o.root_ref & rtd::LEAF_BIT) == 0u) {
-            for (int a = 0; a < 3; ++a) lo[a] = o.surf[a], hi[a] = o.surf[3 + a];
+            continue;  // the object loop's own root-box test is this very test, and costs the same
         } else {
             double m[9], inv[9];  // forward matrix = inverse of the stored inverse; identity without a transform
             for (int a = 0; a < 9; ++a) m[a] = o.has_transform ? (double)o.inv_m[a] : (a % 4 == 0 ? 1.0 : 0.0);
@@ -459,7 +459,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
             wbox[8 * i + a] = (double)l <= lo[a] ? l : std::nextafterf(l, -INFINITY);
             wbox[8 * i + 3 + a] = (double)h >= hi[a] ? h : std::nextafterf(h, INFINITY);
         }
-        if (ok) cull_test |= 1u << i;
+        if (ok) cull_test |= 1ull << i;
     }
     if (s->initial_medium >= (int32_t)s->n_media || s->initial_medium < RT_MEDIUM_AUTO) {
         rth::set_error("rt_upload_scene: initial_medium out of range");

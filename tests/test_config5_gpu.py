@@ -38,7 +38,7 @@ def _rotation(rng):
 
 def test_top_level_cull_changes_nothing(ctx):
     """The flat top level over objects (DScene::wbox, device_trace.h) leaves objects whose world bounds a
-    ray misses out of Engine::hit's loop (path_integrator.rs:88-104).  40 objects -- more than the 32 the
+    ray misses out of Engine::hit's loop (path_integrator.rs:88-104).  70 objects -- more than the 64 the
     candidate mask covers -- with rotated, scaled and translated meshes, a leaf-root mesh, planes and a
     sphere in between; rays through pixel centres, random rays and rays aimed at the corners of every
     object's world bounds.  The culling kernels (no counters) must give the oracle's bits; so must the
@@ -48,9 +48,9 @@ def test_top_level_cull_changes_nothing(ctx):
     mats = [desc.diffuse((0.8, 0.3, 0.2)), desc.dielectric(1.5), desc.diffuse((0.2, 0.3, 0.8))]
     small, big, single = scenes.tetrahedron_mesh(1), scenes.tetrahedron_mesh(3), scenes.tetrahedron_mesh(0)
     corners = []
-    for i in range(40):
-        pos = np.array([(i % 8 - 3.5) * 1.1, (i // 8 - 2.0) * 1.1, 0.3 * np.sin(i)], np.float32)
-        if i in (5, 33):
+    for i in range(70):
+        pos = np.array([(i % 10 - 4.5) * 1.1, (i // 10 - 3.0) * 1.1, 0.3 * np.sin(i)], np.float32)
+        if i in (5, 66):
             desc.add_plane((0.0, 0.0, -1.0 - 0.01 * i), (0.0, 0.0, 1.0), mats[0])
             continue
         if i == 17:
@@ -84,7 +84,7 @@ def test_top_level_cull_changes_nothing(ctx):
     dr = (dr / np.linalg.norm(dr, axis=1, keepdims=True)).astype(np.float32)
 
     o = orc.trace_closest(org, dr)
-    assert len(np.unique(o["obj"])) >= 15 and ((o["obj"] >= 32) & (o["obj"] != rt.api.RT_MISS)).any()
+    assert len(np.unique(o["obj"])) >= 15 and ((o["obj"] >= 64) & (o["obj"] != rt.api.RT_MISS)).any()
     for counters in (False, True):
         g = ctx.trace_closest(org, dr, counters=counters)
         for k in ("obj", "prim", "front_face"):
