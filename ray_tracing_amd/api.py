@@ -237,7 +237,7 @@ class Mesh:
         return v, t
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:  # lib is None once the interpreter shuts down
             lib.rt_mesh_destroy(self.handle)
             self.handle = None
 
@@ -371,7 +371,7 @@ class Scene:
         return [BvhFlat.from_buffer_copy(self.flat.bvhs[i]) for i in range(self.flat.n_bvhs)]
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:
             lib.rt_scene_destroy(self.handle)
             self.handle = None
 
@@ -452,7 +452,7 @@ class Context:
         return out, stats
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:
             lib.rt_destroy(self.handle)
             self.handle = None
 

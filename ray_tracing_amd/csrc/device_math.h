@@ -69,11 +69,13 @@ RT_DEV V3 to_world_coords(V3 dir, V3 normal) {  // bsdf.rs:30-33
 }
 
 // 3x3 row-major (matrix.rs:28-46)
-RT_DEV V3 mat_mul(const float* m, V3 v) {
+template <class P>  // P: pointer to 9 floats in any address space
+RT_DEV V3 mat_mul(P m, V3 v) {
     return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
             m[6] * v.x + m[7] * v.y + m[8] * v.z};
 }
-RT_DEV V3 mat_transpose_mul(const float* m, V3 v) {
+template <class P>
+RT_DEV V3 mat_transpose_mul(P m, V3 v) {
     return {m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
             m[2] * v.x + m[5] * v.y + m[8] * v.z};
 }

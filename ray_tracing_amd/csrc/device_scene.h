@@ -60,6 +60,12 @@ struct DScene {
     unsigned long long cull_test;
 };
 
+// The same records seen through the CONSTANT address space: a load through these with a wave-uniform index
+// is a scalar load (s_load into SGPRs, scalar cache) instead of a vector load that every lane repeats and the
+// wave waits a full vector-memory round trip for.  Only for data no kernel writes (objects, wbox).
+typedef const __attribute__((address_space(4))) DObject CObject;
+typedef const __attribute__((address_space(4))) float CFloat;
+
 struct Visits {
     uint32_t n_int, n_tri;
 };
@@ -96,7 +102,8 @@ struct Stack {
 
 // AxisAlignedBoundingBox::hit (primitives.rs:304-321).  t_min only grows and t_max only shrinks
 // over the three axes, so the per-axis early return is equivalent to one test at the end.
-RT_DEV bool aabb_hit(const float* lo, const float* hi, V3 o, V3 inv, float t_min, float t_max, float* t_entry) {
+template <class P>  // P: pointer to 3 floats in any address space
+RT_DEV bool aabb_hit(P lo, P hi, V3 o, V3 inv, float t_min, float t_max, float* t_entry) {
     {
         float t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
         bool neg = inv.x < 0.0f;

@@ -141,7 +141,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             cand = ~sc.cull_test;
             for (unsigned long long m = sc.cull_test; m != 0ull; m &= m - 1ull) {
                 const uint32_t k = (uint32_t)__builtin_ctzll(m);
-                const float* b = sc.wbox + 8u * k;
+                CFloat* b = (CFloat*)sc.wbox + 8u * k;
                 float t_entry;
                 if (aabb_hit(b, b + 3, wo, winv, t_min, t_max_in, &t_entry)) cand |= 1ull << k;
             }
@@ -299,7 +299,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     }
                     continue;
                 }
-                const DObject& ob = sc.objects[k];
+                CObject& ob = ((CObject*)sc.objects)[k];  // k is uniform: scalar loads
                 if (mine) {
                     obj = k;
                     next = next_cand(k + 1u);
