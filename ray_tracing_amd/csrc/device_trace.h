@@ -229,9 +229,15 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             RT_STAT(1, run);                       // lanes that advance
             RT_STAT(2, n_adv + n_node + n_leaf - run);  // lanes waiting for another phase
             RT_STAT(more ? 3 : 4, 64u - n_adv - n_node - n_leaf);  // idle lanes (queue not empty / draining)
+#if RT_STAT_LANES  // lanes served per phase kind instead of phase counts (divide by the counts of a normal stats run)
+            RT_STAT(5, run_node ? n_node : 0);
+            RT_STAT(6, run_leaf ? n_leaf : 0);
+            RT_STAT(7, run_adv ? n_adv : 0);
+#else
             RT_STAT(5, run_node ? 1 : 0);
             RT_STAT(6, run_leaf ? 1 : 0);
             RT_STAT(7, run_adv ? 1 : 0);
+#endif
         }
 #endif
 
