@@ -75,7 +75,7 @@ struct rt_ctx {
     bool has_scene = false;
     uint32_t features = 0;  // rtd::SceneFeatures the uploaded scene needs
     rtd::DScene scene{};  // host copy of the kernel argument
-    DevBuf pairs, tris, objects, materials, lights, media, wbox;
+    DevBuf pairs, objects, materials, lights, media, wbox;  // pairs: child pairs + triangles (one allocation)
     DevBuf overflow;      // traversal-stack overflow strips
     uint32_t overflow_levels = 0;
     DevBuf staging[16];   // rt_trace_* host<->device staging

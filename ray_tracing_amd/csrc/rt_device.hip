@@ -253,7 +253,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->pairs, &ctx->tris, &ctx->objects, &ctx->materials, &ctx->lights, &ctx->media, &ctx->wbox,
+    DevBuf* bufs[] = {&ctx->pairs, &ctx->objects, &ctx->materials, &ctx->lights, &ctx->media, &ctx->wbox,
                       &ctx->overflow, &ctx->path_state, &ctx->queues, &ctx->counters, &ctx->sample_sum};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->staging) b.release();
