@@ -96,3 +96,23 @@ def test_config4_medium_full_resolution_subset(ctx):
                          np.random.default_rng(4).choice(W * H, 400, replace=False)]).astype(np.uint32)
     ref, _ = orc.render_pixels(W, H, px, 4, 16, 7, threads=8)
     assert np.array_equal(img.reshape(-1, 3)[px].view(np.uint32), ref.view(np.uint32))
+
+
+def test_config5_instances_full_resolution_subset(ctx):
+    """configs[4] pattern at full resolution: a plane and 10 translated instances of one mesh (65 536
+    triangles each here, so that the oracle builds its trees in seconds).  The top level over objects
+    (world-bounds candidate mask) is what this frame exercises: 1 200 random pixels against the oracle."""
+    desc = scenes.multi_mesh_scene(levels=7, copies=10)
+    scene = rt.Scene(desc)
+    ctx.upload(scene)
+    orc = ob.OracleScene(desc)
+    img, st = ctx.render(W, H, 4, 16, 3)
+    assert np.isfinite(img).all() and img.mean() > 0
+    org, dr = scenes.pixel_center_rays(scene.flat.camera, W, H)
+    objs = ctx.trace_closest(org, dr)["obj"]
+    on_mesh = np.flatnonzero((objs != rt.api.RT_MISS) & (objs > 0))
+    assert len(np.unique(objs[on_mesh])) == 10 and len(on_mesh) > 10000
+    px = np.concatenate([np.random.default_rng(5).choice(on_mesh, 800, replace=False),
+                         np.random.default_rng(6).choice(W * H, 400, replace=False)]).astype(np.uint32)
+    ref, _ = orc.render_pixels(W, H, px, 4, 16, 3, threads=8)
+    assert np.array_equal(img.reshape(-1, 3)[px].view(np.uint32), ref.view(np.uint32))
