@@ -222,10 +222,26 @@ RT_DEV float mis_weight(float pa, float pb) {  // path_integrator.rs:30-39, powe
     return a / (a + b);
 }
 
+// Light record l for a wave-uniform l: read through the constant address space (scalar loads into SGPRs, see
+// rtd::CObject) instead of one vector round trip per field.
+RT_DEV rt_light load_light_uniform(const rt_light* lights, uint32_t l) {
+    static_assert(sizeof(rt_light) == 44, "rt_light is copied as 11 dwords");
+    const __attribute__((address_space(4))) uint32_t* p = (const __attribute__((address_space(4))) uint32_t*)(lights + l);
+    uint32_t w[11];
+    for (int i = 0; i < 11; ++i) w[i] = p[i];
+    rt_light out;
+    __builtin_memcpy(&out, w, sizeof out);
+    return out;
+}
+
 // One iteration of the loop body of ray_colour for the path in `slot`.  Returns QF_* flags.
 RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot,
                            uint32_t bounce) {
+    // Everything the slot names is requested at once: nothing below depends on anything but `slot`, and a
+    // wave that waits for each record in turn spends its time in memory round trips (4 waves per SIMD).
     float4 d4 = pa.ray_d[slot], o4, b4;
+    const uint2 hb = pa.hit_b[slot];
+    float4 ha = pa.hit_a[slot];
     if (rp.implicit_first) {  // uniform: the state k_generate left implicit (:139-148)
         o4 = make_float4(sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2], pack_medium(sc.initial_medium, true));
         b4 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rp.depth));
@@ -233,6 +249,17 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         o4 = pa.ray_o[slot];
         b4 = pa.beta[slot];
     }
+    // ... and what the hit names (object record, triangle of a mesh hit) as soon as the hit is here, ahead of the
+    // light tests; a miss reads record 0 / triangle 0 (always mapped) and never looks at them
+    const bool have_hit = hb.x != RT_MISS;
+    const DObject& ob = sc.objects[have_hit ? (hb.x & 0x7FFFFFFFu) : 0u];
+    const uint32_t ob_kind = ob.kind, ob_has_transform = ob.has_transform, ob_material = ob.material;
+    const uint32_t ob_interface = ob.has_medium_interface;
+    const int32_t ob_inside = ob.medium_inside, ob_outside = ob.medium_outside;
+    const uint32_t tri = have_hit ? hb.y : 0u;
+    const float4 q1 = ld16(sc.tris, tri * 48u + 16u), q2 = ld16(sc.tris, tri * 48u + 32u);
+    const rt_material mat = sc.materials[ob_material];  // a copy: requested here, used after the light tests
+
     V3 ro = v3(o4.x, o4.y, o4.z), rd = v3(d4.x, d4.y, d4.z), beta = v3(b4.x, b4.y, b4.z);
     float prev_pdf = d4.w;
     uint32_t depth = __float_as_uint(b4.w);
@@ -244,9 +271,7 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
     uint32_t pixel = slot % rp.npix;
     Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + slot / rp.npix, bounce, 0u};
 
-    uint2 hb = pa.hit_b[slot];
-    bool have_hit = hb.x != RT_MISS;
-    float4 ha = have_hit ? pa.hit_a[slot] : make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+    if (!have_hit) ha = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
     float t_hit = ha.x;  // T_MAX for a miss (:155)
     V3 normal = v3(ha.y, ha.z, ha.w);
 
@@ -256,7 +281,8 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         float t_max = t_hit;
         for (uint32_t l = 0; l < sc.n_lights; ++l) {
             float t;
-            if (light_hit(sc.lights[l], ro, rd, T_MIN, t_max, &t)) {
+            const rt_light lt = load_light_uniform(sc.lights, l);
+            if (light_hit(lt, ro, rd, T_MIN, t_max, &t)) {
                 t_max = t;
                 light = (int)l;
             }
@@ -304,14 +330,10 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         }
     }
 
-    const DObject& ob = sc.objects[hb.x & 0x7FFFFFFFu];
     bool front_face = (hb.x >> 31) != 0;
-    const rt_material& mat = sc.materials[ob.material];
-    if (ob.kind == RT_SURF_MESH) {  // hit_mesh left the normal to us: primitives.rs:175, then object.rs:60-63
-        const uint32_t tri = hb.y;
-        float4 q1 = ld16(sc.tris, tri * 48u + 16u), q2 = ld16(sc.tris, tri * 48u + 32u);
+    if (ob_kind == RT_SURF_MESH) {  // hit_mesh left the normal to us: primitives.rs:175, then object.rs:60-63
         normal = normalise(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));
-        if (ob.has_transform) normal = normalise(mat_transpose_mul(ob.inv_m, normal));
+        if (ob_has_transform) normal = normalise(mat_transpose_mul(ob.inv_m, normal));
     }
     V3 interaction_point = ro + rd * t_hit;
     V3 wo_local = to_shading_coords(-rd, normal);
@@ -322,7 +344,8 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
     if (!bs.is_specular) {  // NEE (:210-238); the visibility test is deferred to shadow-connect
         uint32_t light_index = rng.usize(sc.n_lights);  // sample_lights_uniform (:124-131)
         float select_light_pdf = 1.0f / (float)sc.n_lights;
-        LightSample ls = light_sample(sc.lights[light_index], interaction_point, rng);
+        const rt_light nee_light = sc.n_lights == 1u ? load_light_uniform(sc.lights, 0u) : sc.lights[light_index];
+        LightSample ls = light_sample(nee_light, interaction_point, rng);
         V3 wi_local = to_shading_coords(ls.direction, normal);
         float p_light = ls.pdf * select_light_pdf;
         V3 bsdf_val = bsdf_eval(mat, wi_local, wo_local);
@@ -342,8 +365,8 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
     prev_pdf = bs.pdf;
     V3 nd = to_world_coords(bs.dir_in, normal);
 
-    if (bs.is_transmission && ob.has_medium_interface)  // :252-261
-        medium = front_face ? ob.medium_inside : ob.medium_outside;
+    if (bs.is_transmission && ob_interface)  // :252-261
+        medium = front_face ? ob_inside : ob_outside;
 
     // Russian roulette (:263-272)
     float q = 1.0f - max_elem(beta);
