@@ -110,7 +110,7 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
     unsigned long long n_int, n_tri;
     const float* camera_origin;  // non-null: first bounce with implicit state (RenderParams::implicit_first)
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // returns the path's slot: the ray's tag from here on
-        const uint32_t slot = queue[i];
+        const uint32_t slot = camera_origin ? i : queue[i];  // first bounce: the queue is the identity (k_generate)
         float4 d4 = pa.ray_d[slot];
         if (camera_origin) {  // uniform
             *o = v3(camera_origin[0], camera_origin[1], camera_origin[2]);
@@ -389,7 +389,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
     uint32_t flags = 0;
     if (i < n) {
-        flags = shade_path(sc, pa, rp, queue[i], rp.bounce);
+        // the first bounce's queue is the identity (k_generate): no look-up
+        flags = shade_path(sc, pa, rp, rp.implicit_first ? i : queue[i], rp.bounce);
         pa.qflags[i] = flags;
     }
     // block totals for the compaction scan (wave ballots)
