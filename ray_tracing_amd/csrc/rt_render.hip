@@ -164,6 +164,19 @@ __global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const
 }
 
 // ---------------------------------------------------------------- shadow-connect
+// The NEE term of an unoccluded shadow ray joins the path's radiance (path_integrator.rs:234-236).  Term and
+// radiance are requested together and the sum is stored either way (unchanged bits when p_light was 0): the
+// wave waits for one round trip here, not for two in a row.
+RT_DEV void add_pending_nee(const PathArrays& pa, uint32_t slot) {
+    const float4 c = pa.sh_c[slot];
+    float4 r = pa.rad[slot];
+    const bool add = c.w != 0.0f;  // p_light > 0
+    r.x = add ? r.x + c.x : r.x;
+    r.y = add ? r.y + c.y : r.y;
+    r.z = add ? r.z + c.z : r.z;
+    pa.rad[slot] = r;
+}
+
 struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds its pending NEE term
     PathArrays pa;
     unsigned long long n_int, n_tri;
@@ -179,14 +192,7 @@ struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds it
     RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
     RT_DEV void emit_any(uint32_t slot, bool occluded, const Visits& vis) {
         if (!occluded) {
-            float4 c = pa.sh_c[slot];
-            if (c.w != 0.0f) {  // p_light > 0 (path_integrator.rs:234)
-                float4 r = pa.rad[slot];
-                r.x += c.x;
-                r.y += c.y;
-                r.z += c.z;
-                pa.rad[slot] = r;
-            }
+            add_pending_nee(pa, slot);
         }
         n_int += vis.n_int;
         n_tri += vis.n_tri;
@@ -481,14 +487,7 @@ struct TailIO {
             n_int_sh += vis.n_int;
             n_tri_sh += vis.n_tri;
             if (!occluded) {
-                float4 c = pa.sh_c[slot];
-                if (c.w != 0.0f) {  // p_light > 0 (path_integrator.rs:234)
-                    float4 r = pa.rad[slot];
-                    r.x += c.x;
-                    r.y += c.y;
-                    r.z += c.z;
-                    pa.rad[slot] = r;
-                }
+                add_pending_nee(pa, slot);
             }
         }
         return alive_after ? next_bounce(slot, o, d, any) : false;
@@ -558,14 +557,7 @@ struct MixedIO {
             n_int_sh += vis.n_int;
             n_tri_sh += vis.n_tri;
             if (!occluded) {
-                float4 c = pa.sh_c[slot];
-                if (c.w != 0.0f) {  // p_light > 0 (path_integrator.rs:234)
-                    float4 r = pa.rad[slot];
-                    r.x += c.x;
-                    r.y += c.y;
-                    r.z += c.z;
-                    pa.rad[slot] = r;
-                }
+                add_pending_nee(pa, slot);
             }
         } else {
             n_int += vis.n_int;
