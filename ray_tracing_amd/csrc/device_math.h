@@ -185,8 +185,11 @@ RT_DEV void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        // one 32x32->64 multiply per product (v_mad_u64_u32) instead of a mul_hi and a mul_lo: integer
+        // multiplies are quarter rate and a block has 20 products
+        const unsigned long long p0 = (unsigned long long)M0 * c0, p1 = (unsigned long long)M1 * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0;
         uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
