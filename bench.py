@@ -151,7 +151,7 @@ def main():
                                  flags=rt.api.RENDER_COUNT_VISITS, out=acc.data_ptr())
         last = {}
 
-        ext_ms, ext_launches = [], []
+        ext_ms, ext_launches, mix_ms, mix_launches = [], [], [], []
 
         def step(record, all_stages=False):
             _, st = ctx.render(width, height, args.spp, args.depth, args.seed, spp_first,
@@ -162,6 +162,8 @@ def main():
             if record:  # k_extend is timed by HIP events on the library's stream in every render call
                 ext_ms.append(st.ms_extend)
                 ext_launches.append(st.launches_extend)
+                mix_ms.append(st.ms_tail)  # mixed (shadow + next bounce) and tail launches: timed the same way
+                mix_launches.append(st.launches_tail)
 
         for _ in range(args.warmup):
             step(False)
@@ -181,7 +183,27 @@ def main():
                            + 40 * (st_count.tris_tested - st_count.tris_tested_tail))
         launches = max(1, int(np.mean(ext_launches)))
         ms_extend_timed = float(np.mean(ext_ms))  # average over the K timed frames
-        result.update(kernel="k_extend_lean" if st.lean_kernels else "k_extend", kernel_ms=ms_extend_timed / launches, alg_bytes=alg_bytes_total / launches,
+        # The same traversal loop also runs in the mixed launches (shadow rays of bounce k + rays of bounce k+1):
+        # their algorithmic bytes are those of both kinds of ray they traced.
+        mix_bytes_total = (48 * (st_count.rays_closest_tail + st_count.rays_shadow_tail)
+                           + 64 * (st_count.nodes_visited_tail + st_count.nodes_visited_shadow_tail)
+                           + 40 * (st_count.tris_tested_tail + st_count.tris_tested_shadow_tail))
+        n_mix = max(1, int(np.mean(mix_launches)))
+        ms_mix_timed = float(np.mean(mix_ms))
+        lean_sfx = "_lean" if st.lean_kernels else ""
+        kernels = {
+            "k_extend" + lean_sfx: {"kernel_ms": ms_extend_timed / launches, "alg_bytes": alg_bytes_total / launches,
+                                    "launches": int(launches), "ms_per_frame": ms_extend_timed},
+            "k_mixed" + lean_sfx: {"kernel_ms": ms_mix_timed / n_mix, "alg_bytes": mix_bytes_total / n_mix,
+                                   "launches": int(n_mix), "ms_per_frame": ms_mix_timed},
+        }
+        # `roofline` prices the closest-hit kernel of the largest launches; the mixed launches are listed beside it
+        result["kernels"] = {k: {"achieved_GBs": round(v["alg_bytes"] / (v["kernel_ms"] * 1e-3) / 1e9, 1) if v["kernel_ms"] > 0 else None,
+                                 "frac": round(v["alg_bytes"] / (v["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v["kernel_ms"] > 0 else None,
+                                 "launches": v["launches"], "ms_per_launch": round(v["kernel_ms"], 4),
+                                 "ms_per_frame": round(v["ms_per_frame"], 3), "alg_bytes_per_launch": int(v["alg_bytes"])}
+                             for k, v in kernels.items()}
+        result.update(kernel="k_extend" + lean_sfx, kernel_ms=ms_extend_timed / launches, alg_bytes=alg_bytes_total / launches,
                       launches=int(launches), ms_extend=ms_extend_timed, ms_shadow=st.ms_shadow, ms_shade=st.ms_shade,
                       ms_generate=st.ms_generate, ms_compact=st.ms_compact, ms_tail=st.ms_tail,
                       paths_tail=int(st.paths_tail), ms_device_total=st.ms_total,
@@ -221,9 +243,10 @@ def main():
                          "stream_copy_GBs": round(stream_copy, 1),
                          "kernel": result["kernel"], "kernel_ms": round(result["kernel_ms"], 4),
                          "alg_bytes_per_launch": int(result["alg_bytes"]),
-                         "n_int_per_ray": round(result["n_int_mean"], 3), "n_tri_per_ray": round(result["n_tri_mean"], 3)},
+                         "n_int_per_ray": round(result["n_int_mean"], 3), "n_tri_per_ray": round(result["n_tri_mean"], 3),
+                         **({"traversal_kernels": result["kernels"]} if "kernels" in result else {})},
             "detail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in result.items()
-                       if k not in ("kernel", "alg_bytes")},
+                       if k not in ("kernel", "alg_bytes", "kernels")},
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, desc, scene, width, height)

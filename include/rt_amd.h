@@ -291,6 +291,7 @@ typedef struct rt_stats {
     uint64_t launches_tail;
     float ms_tail;            /* always filled, like ms_extend */
     uint32_t lean_kernels;    /* 1: the scene has no analytic sphere/triangle objects and the lean traversal kernels (k_*_lean) ran */
+    uint64_t nodes_visited_shadow_tail, tris_tested_shadow_tail; /* shadow rays of the mixed / tail launches */
 } rt_stats;
 
 #define RT_RENDER_COUNT_VISITS 1u /* fill nodes_visited / tris_tested (slower kernel variant) */
