@@ -63,7 +63,8 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
 //   hit(i, t, n, meta, prim)               closest-hit rays: a hit closer than any before it on ray i
 //   emit_closest(i, got, vis)              closest-hit ray i is finished
 //   emit_any(i, occluded, vis)             any-hit ray i is finished
-//   TRACE_PATH only:
+//   TRACE_PATH only (CONTINUES = true: next() may continue the lane with another ray, so finished lanes are
+//   parked for a continuation phase; false: next() is called at once and its return value ignored):
 //   first_is_any(i)                        kind of the ray load() returned
 //   next(i, was_any, got, occluded, vis, &o, &d, &any) -> bool
 //                                          ray of item i finished; true = the lane continues with (o, d, any)
@@ -73,10 +74,16 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
 // records what the scene uses and the hot kernels exist in a lean and a full instantiation.
 enum SceneFeatures : uint32_t { FEAT_TRANSFORM = 1u, FEAT_SPHERE_TRIANGLE = 2u, FEAT_ALL = 3u };
 
+template <class IO, bool PATH> struct ParksLanes { static constexpr bool value = false; };
+template <class IO> struct ParksLanes<IO, true> { static constexpr bool value = IO::CONTINUES; };
+
 template <int MODE, bool COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, bool OVERFLOW = true, class IO>
 RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
                        float t_max_in, uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride) {
     constexpr bool PATH = MODE == TRACE_PATH;
+    // A policy whose rays have no continuation (k_mixed: two kinds of ray, each finished for good) is served at
+    // once like the single-kind kernels; only a policy that may hand the lane its NEXT ray parks it for phase D.
+    constexpr bool PARK = ParksLanes<IO, PATH>::value;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64u - lane));
     Stack<STACK_LDS, BLOCK, OVERFLOW> st;
@@ -116,9 +123,14 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
 
     // a ray is finished: hand it to the IO policy now, or (TRACE_PATH) park the lane for phase D
     auto finish = [&](bool occluded) {
-        if constexpr (PATH) {
+        if constexpr (PARK) {
             cur = REF_DONE;
             done_occluded = occluded;
+        } else if constexpr (PATH) {
+            V3 no, nd;
+            bool nany;
+            (void)io.next(ray, lane_any, got, occluded, vis, &no, &nd, &nany);
+            ray = RAY_NONE;
         } else {
             if constexpr (MODE == TRACE_ANY) io.emit_any(ray, occluded, vis);
             else io.emit_closest(ray, got, vis);
@@ -202,17 +214,17 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         // of the next issue slots; only that phase runs in this iteration.
         const bool any = PATH ? lane_any : MODE == TRACE_ANY;
         const bool adv = ray != RAY_NONE && cur == REF_ADVANCE;
-        const bool isdone = PATH && ray != RAY_NONE && cur == REF_DONE;
+        const bool isdone = PARK && ray != RAY_NONE && cur == REF_DONE;
         const bool isnode = ray != RAY_NONE && (cur & LEAF_BIT) == 0u;
         const bool isleaf = ray != RAY_NONE && (cur & LEAF_BIT) != 0u && cur < REF_DONE;
         const uint32_t n_adv = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(adv)), n_node = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(isnode)),
                        n_leaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(isleaf));
-        const uint32_t n_done = PATH ? (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(isdone)) : 0u;
+        const uint32_t n_done = PARK ? (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(isdone)) : 0u;
         if ((n_adv | n_node | n_leaf | n_done) == 0u) break;
         const uint32_t s_adv = n_adv * tune.w_adv, s_node = n_node * tune.w_node, s_leaf = n_leaf * tune.w_leaf;
         // TRACE_PATH: continuations go first once a fifth of the busy lanes wait for one (running every
         // phase in every iteration instead was measured slower: 6.3 ms against 4.0 ms for 219 000 paths)
-        const bool run_done = PATH && n_done > 0u && 4u * n_done >= n_adv + n_node + n_leaf;
+        const bool run_done = PARK && n_done > 0u && 4u * n_done >= n_adv + n_node + n_leaf;
 #ifndef RT_ADV_AT_REFILL
 #define RT_ADV_AT_REFILL 1
 #endif
@@ -243,7 +255,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
 
         RT_CYC(0)
         // ---------------------------------------------------------------- D: continuation (TRACE_PATH)
-        if constexpr (PATH) {
+        if constexpr (PARK) {
             if (run_done && isdone) {
                 bool next_any = false;
                 if (io.next(ray, lane_any, got, done_occluded, vis, &wo, &wd, &next_any)) {

@@ -451,6 +451,7 @@ struct TailIO {
         ((float*)&pa.hit_a[slot])[0] = t;
         pa.hit_b[slot] = make_uint2(meta, tri);
     }
+    static constexpr bool CONTINUES = true;  // next() carries the lane on to the path's shadow ray / next bounce
     RT_DEV bool first_is_any(uint32_t) const { return false; }
     RT_DEV void hit(uint32_t slot, float t, V3 n, uint32_t meta, uint32_t prim) const {
         pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
@@ -534,6 +535,7 @@ struct MixedIO {
     const uint32_t* queue;  // live paths of the NEXT bounce
     uint32_t n_shadow;
     unsigned long long n_int, n_tri, n_int_sh, n_tri_sh;
+    static constexpr bool CONTINUES = false;  // a finished ray is finished: the lane takes a new one
     RT_DEV bool first_is_any(uint32_t i) const { return i < n_shadow; }
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {
         const bool sh = i < n_shadow;
