@@ -468,7 +468,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
 
     // ---- copy
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
-        int r = b.ensure(bytes ? bytes : 64);
+        int r = b.ensure(bytes > 256 ? bytes : 256);  // record 0 of every table is mapped (k_shade reads it on a miss)
         if (r != RT_OK) return r;
         if (bytes) RT_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         return RT_OK;

@@ -264,7 +264,9 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
     const int32_t ob_inside = ob.medium_inside, ob_outside = ob.medium_outside;
     const uint32_t tri = have_hit ? hb.y : 0u;
     const float4 q1 = ld16(sc.tris, tri * 48u + 16u), q2 = ld16(sc.tris, tri * 48u + 32u);
-    const rt_material mat = sc.materials[ob_material];  // a copy: requested here, used after the light tests
+    // a copy: requested here, used after the light tests (a miss reads material 0 and never looks at it; the
+    // tables are at least 256 B each, rt_upload_scene, so record 0 is mapped even in an empty scene)
+    const rt_material mat = sc.materials[have_hit ? ob_material : 0u];
 
     V3 ro = v3(o4.x, o4.y, o4.z), rd = v3(d4.x, d4.y, d4.z), beta = v3(b4.x, b4.y, b4.z);
     float prev_pdf = d4.w;

@@ -117,6 +117,11 @@ def test_edge_cases(ctx):
     with pytest.raises(rt.RtError):
         ctx.render(1, 9, 1, 4)  # the reference divides by (width - 1)
     _check(ctx, desc, 33, 19, 3, 1)  # ragged sizes, depth 1
+    # no object at all: every ray misses (k_shade's up-front record reads must stay inside the tables)
+    empty = scenes.SceneDescription()
+    empty.area_light((0.0, 0.0, 5.0), 1.0, (3.0, 3.0, 3.0))
+    empty.set_camera((0.0, -4.0, 1.0), (0.0, 4.0, 0.5), scenes.ASPECT_RATIO)
+    _check(ctx, empty, 32, 18, 2, 4)
 
 
 def test_device_output_buffer(ctx):
