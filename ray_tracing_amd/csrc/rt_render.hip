@@ -108,12 +108,14 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
     PathArrays pa;
     const uint32_t* queue;
     unsigned long long n_int, n_tri;
-    const float* camera_origin;  // non-null: first bounce with implicit state (RenderParams::implicit_first)
+    bool first;       // first bounce with implicit state (RenderParams::implicit_first): every ray starts at the camera
+    float cam[3];     // ... whose origin travels by value (a pointer into the kernel arguments turns the load of the
+                      // origin into a flat load of a selected address)
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // returns the path's slot: the ray's tag from here on
-        const uint32_t slot = camera_origin ? i : queue[i];  // first bounce: the queue is the identity (k_generate)
+        const uint32_t slot = first ? i : queue[i];  // first bounce: the queue is the identity (k_generate)
         float4 d4 = pa.ray_d[slot];
-        if (camera_origin) {  // uniform
-            *o = v3(camera_origin[0], camera_origin[1], camera_origin[2]);
+        if (first) {  // uniform
+            *o = v3(cam[0], cam[1], cam[2]);
         } else {
             float4 o4 = pa.ray_o[slot];
             *o = v3(o4.x, o4.y, o4.z);
@@ -146,7 +148,7 @@ __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t*
                                                      uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    ExtendIO io{pa, queue, 0ull, 0ull, first ? sc.camera.origin : nullptr};
+    ExtendIO io{pa, queue, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
     trace_loop<TRACE_CLOSEST, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                              lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
@@ -158,7 +160,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const
                                                  uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    ExtendIO io{pa, queue, 0ull, 0ull, first ? sc.camera.origin : nullptr};
+    ExtendIO io{pa, queue, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
     trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                                   lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
