@@ -272,28 +272,28 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         if (run_adv) {
             if (adv) {
                 if (obj_hit) {  // close the mesh traversal that just ended (Object::hit tail, object.rs:56-65)
-                  if constexpr (IO::DEFER_NORMAL) {
-                    // The consumer rebuilds the normal from the triangle (hit_mesh's `tri`), with the same
-                    // arithmetic: no dependent triangle fetch stalls the wave here.  nr is 1 for an object
-                    // without a transform, and t * 1 is t.
-                    const float t = (FEAT & FEAT_TRANSFORM) ? tmax * nr : tmax;
-                    best_t = t;
-                    got = true;
-                    io.hit_mesh(ray, t, obj | (hit_ff ? 0x80000000u : 0u), hit_tri);
-                  } else {
-                    const DObject& ob = sc.objects[obj];
-                    float4 q0 = ld16(sc.tris, hit_tri * 48u), q1 = ld16(sc.tris, hit_tri * 48u + 16u),
-                           q2 = ld16(sc.tris, hit_tri * 48u + 32u);
-                    V3 nrm = normalise(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));  // primitives.rs:175
-                    float t = tmax;
-                    if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {
-                        t = t * nr;
-                        nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
+                    if constexpr (IO::DEFER_NORMAL) {
+                        // The consumer rebuilds the normal from the triangle (hit_mesh's `tri`), with the same
+                        // arithmetic: no dependent triangle fetch stalls the wave here.  nr is 1 for an object
+                        // without a transform, and t * 1 is t.
+                        const float t = (FEAT & FEAT_TRANSFORM) ? tmax * nr : tmax;
+                        best_t = t;
+                        got = true;
+                        io.hit_mesh(ray, t, obj | (hit_ff ? 0x80000000u : 0u), hit_tri);
+                    } else {
+                        const DObject& ob = sc.objects[obj];
+                        float4 q0 = ld16(sc.tris, hit_tri * 48u), q1 = ld16(sc.tris, hit_tri * 48u + 16u),
+                               q2 = ld16(sc.tris, hit_tri * 48u + 32u);
+                        V3 nrm = normalise(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));  // primitives.rs:175
+                        float t = tmax;
+                        if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {
+                            t = t * nr;
+                            nrm = normalise(mat_transpose_mul(ob.inv_m, nrm));
+                        }
+                        best_t = t;
+                        got = true;
+                        io.hit(ray, t, nrm, obj | (hit_ff ? 0x80000000u : 0u), __float_as_uint(q0.w));
                     }
-                    best_t = t;
-                    got = true;
-                    io.hit(ray, t, nrm, obj | (hit_ff ? 0x80000000u : 0u), __float_as_uint(q0.w));
-                  }
                     obj_hit = false;
                 }
             }
