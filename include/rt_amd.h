@@ -294,7 +294,10 @@ typedef struct rt_stats {
     uint64_t nodes_visited_shadow_tail, tris_tested_shadow_tail; /* shadow rays of the mixed / tail launches */
 } rt_stats;
 
-#define RT_RENDER_COUNT_VISITS 1u /* fill nodes_visited / tris_tested (slower kernel variant) */
+#define RT_RENDER_COUNT_VISITS 1u /* fill nodes_visited / tris_tested with the REFERENCE's visits: no root-box
+                                     skip, no top-level cull -- equal to the oracle's counters (slower variant) */
+#define RT_RENDER_COUNT_FETCHES 8u /* fill them with the visits the TIMED kernels perform (root-box skip and
+                                      top-level cull active): the fetches the roofline figure prices */
 #define RT_RENDER_NO_TAIL 4u      /* keep one launch per stage and bounce to the end (no tail kernel) */
 #define RT_RENDER_TIME_STAGES 2u  /* fill every per-stage ms_* field (adds event records); ms_extend is always filled */
 
@@ -308,6 +311,15 @@ int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp_first, 
 
 /* Upper bound on camera paths kept in flight by rt_render (default: sized from free HBM). */
 int rt_set_max_paths_in_flight(rt_ctx* ctx, uint64_t max_paths);
+
+/* What the optional n_int / n_tri outputs of rt_trace_closest / rt_trace_any count.  RT_COUNT_REFERENCE
+   (default): the reference's visits (bvh.rs:256-257, :271-274), root of every mesh included, equal to the
+   oracle's per ray.  RT_COUNT_FETCHES: the visits the non-counting kernels perform (a mesh whose root box or
+   world bounds the ray misses costs none).  Results (t, prim, obj, ...) are the same bits in every mode.
+   No counterpart in the reference; used by bench.py for the roofline figure. */
+#define RT_COUNT_REFERENCE 0u
+#define RT_COUNT_FETCHES 1u
+int rt_set_visit_count_mode(rt_ctx* ctx, uint32_t mode);
 
 /* Device time (ms) of the kernel launched by the most recent rt_trace_closest / rt_trace_any call:
    HIP events recorded on the context stream directly before and after that one launch (staging

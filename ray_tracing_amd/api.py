@@ -19,7 +19,8 @@ MAT_DIFFUSE, MAT_DIELECTRIC, MAT_CONDUCTOR = range(3)
 LIGHT_POINT, LIGHT_SPOT, LIGHT_AREA = range(3)
 MEDIUM_HOMOGENEOUS, MEDIUM_CHECKERED = range(2)
 MEDIUM_NONE, MEDIUM_AUTO = -1, -2
-RENDER_COUNT_VISITS, RENDER_TIME_STAGES, RENDER_NO_TAIL = 1, 2, 4
+RENDER_COUNT_VISITS, RENDER_TIME_STAGES, RENDER_NO_TAIL, RENDER_COUNT_FETCHES = 1, 2, 4, 8
+COUNT_REFERENCE, COUNT_FETCHES = 0, 1
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -123,7 +124,7 @@ EXPORTS = ["rt_mesh_create", "rt_mesh_read_stl", "rt_mesh_loop_subdivide", "rt_m
            "rt_mesh_volume_centroid", "rt_mesh_counts", "rt_mesh_copy_out", "rt_mesh_destroy", "rt_scene_build",
            "rt_scene_view", "rt_scene_destroy", "rt_tonemap_u8", "rt_write_ppm", "rt_create", "rt_destroy",
            "rt_upload_scene", "rt_initial_medium", "rt_trace_closest", "rt_trace_any", "rt_render",
-           "rt_set_max_paths_in_flight", "rt_last_kernel_ms", "rt_stream", "rt_last_error", "rt_version"]
+           "rt_set_max_paths_in_flight", "rt_set_visit_count_mode", "rt_last_kernel_ms", "rt_stream", "rt_last_error", "rt_version"]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: build it with `make -C ray_tracing_amd/csrc` "
@@ -167,6 +168,7 @@ lib.rt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_ui
                           C.c_uint32, C.c_void_p, C.POINTER(Stats)]
 lib.rt_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneFlat)]
 lib.rt_set_max_paths_in_flight.argtypes = [C.c_void_p, C.c_uint64]
+lib.rt_set_visit_count_mode.argtypes = [C.c_void_p, C.c_uint32]
 
 
 def _check(code):
@@ -404,6 +406,9 @@ class Context:
 
     def set_max_paths_in_flight(self, n):
         _check(lib.rt_set_max_paths_in_flight(self.handle, n))
+
+    def set_visit_count_mode(self, mode):
+        _check(lib.rt_set_visit_count_mode(self.handle, mode))
 
     def trace_closest(self, origins, directions, t_min=1e-3, t_max=np.inf, counters=False):
         o = _f32(origins).reshape(-1, 3)

@@ -77,7 +77,12 @@ enum SceneFeatures : uint32_t { FEAT_TRANSFORM = 1u, FEAT_SPHERE_TRIANGLE = 2u, 
 template <class IO, bool PATH> struct ParksLanes { static constexpr bool value = false; };
 template <class IO> struct ParksLanes<IO, true> { static constexpr bool value = IO::CONTINUES; };
 
-template <int MODE, bool COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, bool OVERFLOW = true, class IO>
+// COUNT: 0 = no visit counters; COUNT_REFERENCE = the reference's visits (no root-box skip, no top-level cull:
+// equal to the oracle's counters ray for ray); COUNT_FETCHES = the visits this loop performs when it is timed
+// (root-box skip and cull active), i.e. the fetches the roofline figure prices.
+enum CountMode { COUNT_NONE = 0, COUNT_REFERENCE = 1, COUNT_FETCHES = 2 };
+
+template <int MODE, int COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, bool OVERFLOW = true, class IO>
 RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
                        float t_max_in, uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride) {
     constexpr bool PATH = MODE == TRACE_PATH;
@@ -147,21 +152,27 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         if (COUNT) vis = {0, 0};
         // Top level: one slab test per bounded object against the WORLD ray, before any per-object transform.
         // Objects whose bounds the ray misses drop out of Engine::hit's loop for this ray; the others are
-        // still met in vector order with the reference's shrinking t_max.  Not when counting visits.
-        if (!COUNT && sc.cull_test != 0ull) {  // uniform
+        // still met in vector order with the reference's shrinking t_max.  Not when counting reference visits.
+        // The test runs over the whole half-line t > 0, not over (t_min, t_max): Object::hit hands the limits
+        // UNSCALED to the object-space ray (object.rs:39-47), so under a scaling transform object k accepts the
+        // world range (t_min * nr, t_max * nr) with nr = 1 / |M^-1 d| depending on the ray -- a mesh scaled x2 is
+        // hit at world t = 1.5 with t_max = 1.  Every accepted hit has t_obj > t_min, hence world t > 0 when
+        // t_min >= 0 (a negative t_min opens the line backwards as well).
+        if (COUNT != COUNT_REFERENCE && sc.cull_test != 0ull) {  // uniform
             const V3 winv = v3(recip(wd.x), recip(wd.y), recip(wd.z));
+            const float w_lo = t_min < 0.0f ? -__builtin_inff() : 0.0f;
             cand = ~sc.cull_test;
             for (unsigned long long m = sc.cull_test; m != 0ull; m &= m - 1ull) {
                 const uint32_t k = (uint32_t)__builtin_ctzll(m);
                 CFloat* b = (CFloat*)sc.wbox + 8u * k;
                 float t_entry;
-                if (aabb_hit(b, b + 3, wo, winv, t_min, t_max_in, &t_entry)) cand |= 1ull << k;
+                if (aabb_hit(b, b + 3, wo, winv, w_lo, __builtin_inff(), &t_entry)) cand |= 1ull << k;
             }
         }
     };
     // the first object >= from that the ray can hit (objects past the 64th are always candidates)
     auto next_cand = [&](uint32_t from) -> uint32_t {
-        if (COUNT) return from;
+        if (COUNT == COUNT_REFERENCE) return from;
         const unsigned long long rem = from < 64u ? cand & (~0ull << from) : 0ull;
         return rem != 0ull ? (uint32_t)__builtin_ctzll(rem) : max(from, 64u);
     };
@@ -340,10 +351,10 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                         // of AABB::hit is monotone in the bounds, so a ray that fails the root test
                         // fails both child tests with the same arithmetic.  No triangle is tested in
                         // either case: the result is identical, one node visit and two phase changes
-                        // cheaper.  Not applied when counting visits (those stay the reference's) or
+                        // cheaper.  Not applied when counting REFERENCE visits (those stay the reference's) or
                         // when the root is itself a leaf.
                         bool enter = true;
-                        if (!COUNT && (ob.root_ref & LEAF_BIT) == 0u) {
+                        if (COUNT != COUNT_REFERENCE && (ob.root_ref & LEAF_BIT) == 0u) {
                             float t_entry;
                             enter = aabb_hit(&ob.surf[0], &ob.surf[3], o, inv, t_min, t_lim, &t_entry);
                         }
@@ -425,28 +436,27 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         if (run_leaf) {
             if (isleaf) {
                 uint32_t k = cur & ~LEAF_BIT;
-                uint32_t last;
-                bool done = false;
-                do {  // primitives in `indices` order (bvh.rs:256-266)
+                bool go_on = true, occluded = false;
+                // primitives in `indices` order (bvh.rs:256-266).  One exit condition, evaluated at the end of
+                // the body: an any-hit lane leaving through a `break` while closest-hit lanes of the same wave
+                // go on made the visit counter of TRACE_PATH instantiations count one test too many.
+                while (go_on) {
                     float4 q0 = ld16(sc.tris, k * 48u), q1 = ld16(sc.tris, k * 48u + 16u), q2 = ld16(sc.tris, k * 48u + 32u);
                     if (COUNT) vis.n_tri += 1;
                     float t, det;
-                    if (tri_hit(v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), o, d, t_min, tmax, &t,
-                                &det)) {
-                        if (any) {
-                            finish(true);
-                            done = true;
-                            break;
-                        }
+                    const bool h = tri_hit(v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), o, d, t_min, tmax, &t, &det);
+                    if (h && !any) {
                         tmax = t;
                         hit_tri = k;
                         hit_ff = det > 0.0f;
                         obj_hit = true;
                     }
-                    last = __float_as_uint(q1.w);
+                    occluded = h && any;
+                    go_on = !occluded && __float_as_uint(q1.w) == 0u;
                     ++k;
-                } while (!last);
-                if (!done) cur = st.sp == 0 ? REF_ADVANCE : st.pop();
+                }
+                if (occluded) finish(true);
+                else cur = st.sp == 0 ? REF_ADVANCE : st.pop();
             }
         }
         RT_CYC(3)

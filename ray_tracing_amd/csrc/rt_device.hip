@@ -114,7 +114,7 @@ struct TraceIO {  // caller-provided SoA ray batch and hit arrays (rt_rays / rt_
     }
 };
 
-template <bool ANY, bool COUNT>
+template <bool ANY, int COUNT>
 __global__ RT_TRACE_ATTR void k_trace(DScene sc, TraceIO io, uint32_t n, float t_min, float t_max,
                                                     uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                     uint32_t overflow_stride) {
@@ -566,14 +566,48 @@ int rt_initial_medium(const rt_ctx* ctx, int32_t* out) {
     return RT_OK;
 }
 
+// One closest-hit / any-hit launch over device-resident arrays: the part rt_trace_* and rt_trace_*_noalloc share.
+// `work` = WORK_U32 zeroed work counters, `overflow` = traversal-stack overflow strips for `lanes` lanes.
+static int launch_trace(rt_ctx* ctx, bool any, const TraceIO& io, size_t n, float t_min, float t_max, int grid,
+                        uint32_t* work, uint32_t* overflow, uint32_t lanes) {
+    const bool want_count = io.out.n_int || io.out.n_tri;
+    const int count = !want_count ? COUNT_NONE : (ctx->count_mode == RT_COUNT_FETCHES ? COUNT_FETCHES : COUNT_REFERENCE);
+    const TraceTune tune = rt_trace_tune(n, grid);
+#define RT_LAUNCH_TRACE(...)                                                                                           \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io, (uint32_t)n, t_min, t_max, \
+                       work, tune, overflow, lanes)
+    RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (any) {
+        if (count == COUNT_REFERENCE) RT_LAUNCH_TRACE(k_trace<true, COUNT_REFERENCE>);
+        else if (count == COUNT_FETCHES) RT_LAUNCH_TRACE(k_trace<true, COUNT_FETCHES>);
+        else if (rt_scene_is_lean(ctx)) RT_LAUNCH_TRACE(k_trace_lean<true>);
+        else RT_LAUNCH_TRACE(k_trace<true, COUNT_NONE>);
+    } else {
+        if (count == COUNT_REFERENCE) RT_LAUNCH_TRACE(k_trace<false, COUNT_REFERENCE>);
+        else if (count == COUNT_FETCHES) RT_LAUNCH_TRACE(k_trace<false, COUNT_FETCHES>);
+        else if (rt_scene_is_lean(ctx)) RT_LAUNCH_TRACE(k_trace_lean<false>);
+        else RT_LAUNCH_TRACE(k_trace<false, COUNT_NONE>);
+    }
+#undef RT_LAUNCH_TRACE
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    return RT_OK;
+}
+
+static bool rays_null(const rt_rays* r) { return !r || !r->ox || !r->oy || !r->oz || !r->dx || !r->dy || !r->dz; }
+
 int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, const rt_hits* hits) {
     int rc = check_ctx(ctx, true);
     if (rc != RT_OK) return rc;
-    if (!rays || !hits || !hits->t || !rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz) {
+    if (rays_null(rays) || !hits || !hits->t) {
         rth::set_error("rt_trace_closest: null argument");
         return RT_ERR_INVALID;
     }
     if (n == 0) return RT_OK;
+    if (n > 0xFFFFFFF0ull) {
+        rth::set_error("rt_trace_closest: batch larger than 2^32 rays");
+        return RT_ERR_LIMIT;
+    }
     Stager sg{ctx};
     rt_rays dr;
     rt_hits dh;
@@ -588,35 +622,15 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
         (rc = sg.out(hits->front_face, n, (void**)&dh.front_face)) ||
         (rc = sg.out(hits->n_int, fb, (void**)&dh.n_int)) || (rc = sg.out(hits->n_tri, fb, (void**)&dh.n_tri)))
         return rc;
-    if (n > 0xFFFFFFF0ull) {
-        rth::set_error("rt_trace_closest: batch larger than 2^32 rays");
-        return RT_ERR_LIMIT;
-    }
-    int grid = trace_grid(n);
-    size_t lanes = (size_t)grid * RT_BLOCK;
+    const int grid = trace_grid(n);
+    const size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
     if ((rc = ctx->counters.ensure(WORK_U32 * 4)) != RT_OK) return rc;
     RT_HIP(hipMemsetAsync(ctx->counters.p, 0, WORK_U32 * 4, ctx->stream));
-    bool count = dh.n_int || dh.n_tri;
     TraceIO io{dr, dh, nullptr};
-    RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (count)
-        hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
-                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
-                           (uint32_t*)ctx->overflow.p,
-                           (uint32_t)lanes);
-    else if (rt_scene_is_lean(ctx))
-        hipLaunchKernelGGL((k_trace_lean<false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
-                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
-                           (uint32_t*)ctx->overflow.p,
-                           (uint32_t)lanes);
-    else
-        hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
-                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
-                           (uint32_t*)ctx->overflow.p,
-                           (uint32_t)lanes);
-    RT_HIP(hipGetLastError());
-    RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    if ((rc = launch_trace(ctx, false, io, n, t_min, t_max, grid, (uint32_t*)ctx->counters.p, (uint32_t*)ctx->overflow.p,
+                           (uint32_t)lanes)) != RT_OK)
+        return rc;
     if ((rc = sg.finish()) != RT_OK) return rc;
     RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
     return RT_OK;
@@ -626,11 +640,15 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
                  uint32_t* n_int, uint32_t* n_tri) {
     int rc = check_ctx(ctx, true);
     if (rc != RT_OK) return rc;
-    if (!rays || !occluded || !rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz) {
+    if (rays_null(rays) || !occluded) {
         rth::set_error("rt_trace_any: null argument");
         return RT_ERR_INVALID;
     }
     if (n == 0) return RT_OK;
+    if (n > 0xFFFFFFF0ull) {
+        rth::set_error("rt_trace_any: batch larger than 2^32 rays");
+        return RT_ERR_LIMIT;
+    }
     Stager sg{ctx};
     rt_rays dr;
     uint8_t* d_occ;
@@ -643,12 +661,8 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
     if ((rc = sg.out(occluded, n, (void**)&d_occ)) || (rc = sg.out(n_int, fb, (void**)&d_ni)) ||
         (rc = sg.out(n_tri, fb, (void**)&d_nt)))
         return rc;
-    if (n > 0xFFFFFFF0ull) {
-        rth::set_error("rt_trace_any: batch larger than 2^32 rays");
-        return RT_ERR_LIMIT;
-    }
-    int grid = trace_grid(n);
-    size_t lanes = (size_t)grid * RT_BLOCK;
+    const int grid = trace_grid(n);
+    const size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
     if ((rc = ctx->counters.ensure(WORK_U32 * 4)) != RT_OK) return rc;
     RT_HIP(hipMemsetAsync(ctx->counters.p, 0, WORK_U32 * 4, ctx->stream));
@@ -657,26 +671,20 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
     dh.n_int = d_ni;
     dh.n_tri = d_nt;
     TraceIO io{dr, dh, d_occ};
-    RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (d_ni || d_nt)
-        hipLaunchKernelGGL((k_trace<true, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
-                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
-                           (uint32_t*)ctx->overflow.p,
-                           (uint32_t)lanes);
-    else if (rt_scene_is_lean(ctx))
-        hipLaunchKernelGGL((k_trace_lean<true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
-                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
-                           (uint32_t*)ctx->overflow.p,
-                           (uint32_t)lanes);
-    else
-        hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->scene, io,
-                           (uint32_t)n, t_min, t_max, (uint32_t*)ctx->counters.p, rt_trace_tune(n, grid),
-                           (uint32_t*)ctx->overflow.p,
-                           (uint32_t)lanes);
-    RT_HIP(hipGetLastError());
-    RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    if ((rc = launch_trace(ctx, true, io, n, t_min, t_max, grid, (uint32_t*)ctx->counters.p, (uint32_t*)ctx->overflow.p,
+                           (uint32_t)lanes)) != RT_OK)
+        return rc;
     if ((rc = sg.finish()) != RT_OK) return rc;
     RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
+    return RT_OK;
+}
+
+int rt_set_visit_count_mode(rt_ctx* ctx, uint32_t mode) {
+    if (!ctx || mode > RT_COUNT_FETCHES) {
+        rth::set_error("rt_set_visit_count_mode: bad argument");
+        return RT_ERR_INVALID;
+    }
+    ctx->count_mode = mode;
     return RT_OK;
 }
 

@@ -136,13 +136,16 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
     }
     RT_DEV void emit_closest(uint32_t slot, bool got, const Visits& vis) {
         if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
+#if RT_DEBUG_COUNT_IMAGE  // diagnostics build: the red channel of the image is the path's closest-hit triangle-test count
+        ((float*)&pa.rad[slot])[3] += (float)vis.n_tri;
+#endif
         n_int += vis.n_int;
         n_tri += vis.n_tri;
     }
     RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
 };
 
-template <bool COUNT>
+template <int COUNT>
 __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n, uint32_t first,
                                                      uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                      uint32_t overflow_stride) {
@@ -202,7 +205,7 @@ struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds it
 };
 
 // path_integrator.rs:219: the shadow ray is tested over T_MIN..T_MAX, not up to the light.
-template <bool COUNT>
+template <int COUNT>
 __global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, uint32_t n, uint32_t* work_counter,
                                                      TraceTune tune, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_ANY * RT_BLOCK];
@@ -477,6 +480,9 @@ struct TailIO {
         if (!was_any) {
             n_int += vis.n_int;
             n_tri += vis.n_tri;
+#if RT_DEBUG_COUNT_IMAGE
+            ((float*)&pa.rad[slot])[3] += (float)vis.n_tri;
+#endif
             if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
             const uint32_t flags = shade_path(*sc, pa, *rp, slot, rp->bounce + iters - 1u);
             alive_after = (flags & QF_ALIVE) != 0;
@@ -505,7 +511,7 @@ RT_DEV unsigned long long wave_sum_u64(unsigned long long v) {
 }
 
 // pa.tail[0..7]: closest rays, shadow rays, n_int, n_tri (closest), n_int, n_tri (shadow), max iterations, unused
-template <bool COUNT>
+template <int COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, RenderParams rp, const uint32_t* queue,
                                                    uint32_t n, uint32_t* work_counter, TraceTune tune,
                                                    uint32_t* overflow, uint32_t overflow_stride) {
@@ -576,7 +582,7 @@ struct MixedIO {
     }
 };
 
-template <bool COUNT>
+template <int COUNT>
 __global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n_shadow, uint32_t n,
                                       uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                       uint32_t overflow_stride) {
@@ -707,6 +713,9 @@ __global__ __launch_bounds__(256) void k_resolve(PathArrays pa, float* rgb_sum, 
     }
     for (uint32_t s = 0; s < s_count; ++s) {
         float4 r = pa.rad[(size_t)s * npix + pixel];
+#if RT_DEBUG_COUNT_IMAGE
+        r.x = r.w;
+#endif
         cx += r.x;
         cy += r.y;
         cz += r.z;
@@ -833,7 +842,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     const uint32_t ostride = (uint32_t)trace_grid_max * RT_BLOCK;
     uint32_t* overflow = (uint32_t*)ctx->overflow.p;
 
-    const bool count = (flags & RT_RENDER_COUNT_VISITS) != 0;
+    // visit counters: the reference's visits (equal to the oracle's) or the fetches the timed kernels perform
+    const int count = (flags & RT_RENDER_COUNT_VISITS) ? rtd::COUNT_REFERENCE : (flags & RT_RENDER_COUNT_FETCHES) ? rtd::COUNT_FETCHES : rtd::COUNT_NONE;
     const bool use_tail = (flags & RT_RENDER_NO_TAIL) == 0;
     // scenes without analytic sphere / triangle objects (meshes, planes, transforms) take the lean kernels
     static const uint64_t mix_paths = [] {  // RT_MIX_PATHS: rays (shadow + next bounce) up to which they share a launch
@@ -927,11 +937,14 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             if (use_tail && n <= tail_paths) {  // few paths left: one launch takes them to their end
                 RT_HIP(hipMemsetAsync(pa.tail + 6, 0, 8, stream));
                 if ((rc = t_begin(5)) != RT_OK) return rc;
-                if (count)
-                    hipLaunchKernelGGL(k_tail<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
+                if (count == rtd::COUNT_REFERENCE)
+                    hipLaunchKernelGGL(k_tail<rtd::COUNT_REFERENCE>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
+                                       pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
+                else if (count == rtd::COUNT_FETCHES)
+                    hipLaunchKernelGGL(k_tail<rtd::COUNT_FETCHES>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
                                        pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
                 else
-                    hipLaunchKernelGGL(k_tail<false>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
+                    hipLaunchKernelGGL(k_tail<rtd::COUNT_NONE>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
                                        pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
                 if ((rc = t_end(5)) != RT_OK) return rc;
                 unsigned long long tail_iters = 0;
@@ -945,14 +958,17 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             }
             if (!extend_done) {
             if ((rc = t_begin(1)) != RT_OK) return rc;
-            if (count)
-                hipLaunchKernelGGL(k_extend<true>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+            if (count == rtd::COUNT_REFERENCE)
+                hipLaunchKernelGGL(k_extend<rtd::COUNT_REFERENCE>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                                   pa.queue[cur], n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
+            else if (count == rtd::COUNT_FETCHES)
+                hipLaunchKernelGGL(k_extend<rtd::COUNT_FETCHES>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
                                    pa.queue[cur], n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
             else if (lean)
                 hipLaunchKernelGGL(k_extend_lean, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, pa.queue[cur],
                                    n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
             else
-                hipLaunchKernelGGL(k_extend<false>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                hipLaunchKernelGGL(k_extend<rtd::COUNT_NONE>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
                                    pa.queue[cur], n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
             if ((rc = t_end(1)) != RT_OK) return rc;
             st.rays_closest += n;
@@ -988,8 +1004,12 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                 const uint32_t n_mix = n_shadow + n_next;
                 const int mgrid = (int)std::min<uint32_t>((n_mix + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
                 if ((rc = t_begin(5)) != RT_OK) return rc;
-                if (count)
-                    hipLaunchKernelGGL(k_mixed<true>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                if (count == rtd::COUNT_REFERENCE)
+                    hipLaunchKernelGGL(k_mixed<rtd::COUNT_REFERENCE>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                                       pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
+                                       rt_trace_tune(n_mix, mgrid), overflow, ostride);
+                else if (count == rtd::COUNT_FETCHES)
+                    hipLaunchKernelGGL(k_mixed<rtd::COUNT_FETCHES>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
                                        pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
                                        rt_trace_tune(n_mix, mgrid), overflow, ostride);
                 else if (lean)
@@ -997,7 +1017,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                                        pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
                                        rt_trace_tune(n_mix, mgrid), overflow, ostride);
                 else
-                    hipLaunchKernelGGL(k_mixed<false>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                    hipLaunchKernelGGL(k_mixed<rtd::COUNT_NONE>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
                                        pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
                                        rt_trace_tune(n_mix, mgrid), overflow, ostride);
                 if ((rc = t_end(5)) != RT_OK) return rc;
@@ -1010,14 +1030,17 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             } else if (n_shadow > 0) {
                 const int sgrid = (int)std::min<uint32_t>((n_shadow + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
                 if ((rc = t_begin(3)) != RT_OK) return rc;
-                if (count)
-                    hipLaunchKernelGGL(k_shadow<true>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
+                if (count == rtd::COUNT_REFERENCE)
+                    hipLaunchKernelGGL(k_shadow<rtd::COUNT_REFERENCE>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
+                                       pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
+                else if (count == rtd::COUNT_FETCHES)
+                    hipLaunchKernelGGL(k_shadow<rtd::COUNT_FETCHES>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
                                        pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
                 else if (lean)
                     hipLaunchKernelGGL(k_shadow_lean, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
                                        pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
                 else
-                    hipLaunchKernelGGL(k_shadow<false>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
+                    hipLaunchKernelGGL(k_shadow<rtd::COUNT_NONE>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
                                        n_shadow, pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
                 if ((rc = t_end(3)) != RT_OK) return rc;
                 st.rays_shadow += n_shadow;
@@ -1071,8 +1094,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
 
 #if RT_TRACE_STATS
 extern "C" int rt_debug_occupancy(int* out4) {  // resident workgroups per CU: extend, shadow, extend_lean, shade
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_extend<false>, RT_BLOCK, 0) != hipSuccess) return -2;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_shadow<false>, RT_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_extend<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_shadow<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend_lean, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_shade, SHADE_BLOCK, 0) != hipSuccess) return -2;
     return 0;

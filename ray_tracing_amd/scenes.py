@@ -123,6 +123,63 @@ def primitives_scene():
     return s
 
 
+def baby_yoda_scene(stl_path, sigma_s=0.0, extra_mesh_levels=None):
+    """scene_baby_yoda, src/main.rs:214-299: the STL mesh (read_stl, stl.rs:8-143; 4 120 triangles) as
+    Dielectric{1.5} with a HomogeneousMedium inside (sigma_a (0.03, 0.03, 0.01); sigma_s 0 in the reference),
+    ground plane at the mesh's lowest vertex, a floating diffuse ball (unit sphere under scale_translate(5,
+    (-4, 6, 59))), one far sphere AreaLight.  `extra_mesh_levels`: SURVEY.md's config 3 puts the subdivided
+    tetrahedron (Diffuse (1, 0.5, 0.5)) beside it -- added scaled x48 next to the figure when given."""
+    s = SceneDescription()
+    mesh = Mesh.read_stl(stl_path)
+    verts = mesh.arrays()[0]
+    ground = F(np.min(verts[:, 2]))
+    centre = mesh.volume_centroid()
+    glass = s.dielectric(1.5)
+    med = s.homogeneous_medium((0.03, 0.03, 0.01), (sigma_s, sigma_s, sigma_s), 0.0, (0.0, 0.0, 0.0))
+    s.add_mesh(mesh, glass, medium=(med, None))
+    s.add_plane((0.0, 0.0, float(ground)), (0.0, 0.0, 1.0), s.diffuse((0.8, 0.8, 0.8)))
+    ball = s.diffuse(tuple(np.array([0.8, 0.2, 0.2], np.float32) * F(2.0)))
+    s.add_sphere((0.0, 0.0, 0.0), 1.0, ball, transform=(IDENTITY * F(5.0), (-4.0, 6.0, 59.0)))
+    # camera: centre + 90 * new_polar(1, pi/2, 0.4 pi) + 40 Z, looking at the centroid (:252-260)
+    d = new_polar(1.0, PI / F(2.0), F(0.4) * PI)
+    origin = ((centre + F(90.0) * d).astype(np.float32) + F(40.0) * np.array([0, 0, 1], np.float32)).astype(np.float32)
+    s.look_at(origin, centre, ASPECT_RATIO)
+    away = (centre - origin).astype(np.float32)  # Camera::get_direction: normalised (camera.rs:44-46)
+    n2 = (away[0] * away[0] + away[1] * away[1]) + away[2] * away[2]
+    away = (away * (F(1.0) / np.sqrt(F(n2)))).astype(np.float32)
+    z = np.array([0, 0, 1], np.float32)
+    left = np.cross(z, away).astype(np.float32)
+    away[2] = F(0.0)
+    lc = (((centre + F(2000.0) * z).astype(np.float32) + F(2000.0) * left).astype(np.float32) - F(1000.0) * away).astype(np.float32)
+    s.area_light(tuple(lc), 1000.0, (5.0, 5.0, 5.0))
+    if extra_mesh_levels is not None:
+        pos = (centre - F(60.0) * left).astype(np.float32)
+        s.add_mesh(tetrahedron_mesh(extra_mesh_levels), s.diffuse((1.0, 0.5, 0.5)),
+                   transform=(IDENTITY * F(48.0), (float(pos[0]), float(pos[1]), float(ground) + 17.0)))
+    return s
+
+
+def spotlight_scene(levels=3):
+    """Spotlight (lights.rs:49-75) next to a PointLight: a subdivided tetrahedron and a glass ball over a ground
+    plane.  The cone (cos_angle 0.9) covers the mesh and part of the plane, so shading points fall on both sides
+    of the `-dot(direction, dir) > cos_angle` test; the spotlight's intensity is NOT divided by the squared
+    distance (the reference normalises before it takes d2, lights.rs:59-61), hence the modest value."""
+    s = SceneDescription()
+    red = s.diffuse((1.0, 0.5, 0.5))
+    grey = s.diffuse((0.8, 0.8, 0.8))
+    s.add_mesh(tetrahedron_mesh(levels), red)
+    s.add_plane((0.0, 0.0, -0.6), (0.0, 0.0, 1.0), grey)
+    s.add_sphere((0.9, -0.9, -0.25), 0.35, s.dielectric(1.5))
+    pos = np.array([2.0, -1.5, 4.0], np.float32)
+    aim = (np.array([0.2, -0.2, -0.3], np.float32) - pos).astype(np.float32)
+    aim = (aim / np.sqrt((aim * aim).sum(dtype=np.float32))).astype(np.float32)
+    s.spotlight(pos, aim, 0.9, (2.5, 2.4, 2.0))
+    s.point_light((-30.0, -20.0, 40.0), (900.0, 900.0, 1200.0))
+    loc = new_polar(4.0, F(0.3) * PI, F(-0.4) * PI)
+    s.look_at(loc, (0.2, -0.3, -0.3), ASPECT_RATIO)
+    return s
+
+
 def image_height(width, aspect=ASPECT_RATIO):
     """(image_width as f32 / aspect_ratio) as usize, path_integrator.rs:285"""
     return int(F(width) / F(aspect))

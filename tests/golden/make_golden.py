@@ -5,7 +5,7 @@ fixtures for traversal or rendering, so these files pin the ORACLE against drift
 later edits) and give the GPU tests expected outputs that do not depend on running the oracle.  The
 reference's own known-answer tests are restated inline in tests/test_oracle_golden.py.
 
-    python tests/golden/make_golden.py        # rewrites the fixtures (commit the result)
+    python tests/golden/make_golden.py [name ...]   # rewrites the fixtures (all, or the named ones); commit the result
 """
 import os, sys
 import numpy as np
@@ -22,6 +22,8 @@ CASES = {  # name -> (scene description factory, width, spp, depth, seed)
     "config3_area_light_dielectric": (lambda: scenes.path_scene(levels=3, glass_levels=2), 64, 4, 16, 13),
     "config4_homogeneous_medium": (lambda: scenes.path_scene(levels=3, glass_levels=2, medium=True, sigma_s=2.0), 48, 4, 16, 14),
     "primitives_conductor": (lambda: scenes.primitives_scene(), 64, 4, 16, 15),
+    "stl_baby_yoda_medium": (lambda: scenes.baby_yoda_scene(os.path.join(HERE, "baby_yoda.stl"), sigma_s=0.05, extra_mesh_levels=3), 64, 4, 16, 17),
+    "spotlight_and_point_light": (lambda: scenes.spotlight_scene(levels=3), 64, 4, 16, 16),
 }
 
 
@@ -33,7 +35,7 @@ def build(name):
 
 
 def main():
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):
         desc, w, h, spp, depth, seed = build(name)
         orc = ob.OracleScene(desc)
         img, st = orc.render(w, h, spp, depth, seed, 0)

@@ -100,3 +100,74 @@ def test_top_level_cull_changes_nothing(ctx):
     ref, ost = orc.render(96, 54, 4, 16, 9)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     assert (st.rays_closest, st.rays_shadow) == (ost.rays_closest, ost.rays_shadow)
+
+
+def test_scaled_objects_keep_the_unscaled_t_range(ctx):
+    """Object::hit hands t_min/t_max UNSCALED to the object-space ray (object.rs:39-47): a mesh scaled x2 accepts
+    world t in (2 t_min, 2 t_max), one scaled x0.3 accepts (0.3 t_min, 0.3 t_max).  The top-level cull must not
+    drop an object the reference would still hit -- e.g. the x2 mesh entered at world t = 1.5 with t_max = 1.
+    Culling kernels (no counters) == reference-counting kernels (no cull) == fetch-counting kernels == oracle,
+    bit for bit, over finite t ranges, for rays that start 0.5-3 units from each object's bounds and for rays
+    that leave the surface next to the extreme vertices of the bounds."""
+    rng = np.random.default_rng(23)
+    desc = scenes.SceneDescription()
+    mats = [desc.diffuse((0.8, 0.3, 0.2)), desc.dielectric(1.5)]
+    mesh, single = scenes.tetrahedron_mesh(3), scenes.tetrahedron_mesh(0)
+    verts = mesh.arrays()[0]
+    placements = [(2.0, (-3.0, 0.0, 0.0), mesh), (0.3, (1.5, 0.0, 0.0), mesh), (2.0, (0.0, 4.0, 0.5), single),
+                  (0.3, (0.0, -2.0, 0.0), single), (1.0, (3.5, 2.0, 0.0), mesh)]
+    org, dr = [], []
+    for i, (scale, pos, m) in enumerate(placements):
+        rot = _rotation(rng) if i != 4 else np.eye(3, dtype=np.float32)
+        mat = (rot * np.float32(scale)).astype(np.float32)
+        desc.add_mesh(m, mats[i % 2], transform=(mat, pos))
+        wv = (verts @ mat.T + np.array(pos, np.float32)).astype(np.float32)  # world-space vertices
+        centre, radius = wv.mean(0), np.linalg.norm(wv - wv.mean(0), axis=1).max()
+        # rays from 0.5 .. 3 units outside the bounding sphere towards points of the mesh
+        n = 1500
+        u = rng.normal(size=(n, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        o = centre + u * (radius + rng.uniform(0.5, 3.0, size=(n, 1)))
+        tgt = wv[rng.integers(0, len(wv), n)] + rng.normal(scale=0.02 * scale, size=(n, 3))
+        org.append(o)
+        dr.append(tgt - o)
+        # rays leaving the surface next to the extreme vertices of the world bounds (hits at tiny t, next to the box exit)
+        ext = np.concatenate([wv[wv[:, a].argmin()][None] for a in range(3)] + [wv[wv[:, a].argmax()][None] for a in range(3)])
+        o = np.repeat(ext, 60, 0) + rng.normal(scale=2e-3 * scale, size=(360, 3))
+        org.append(o)
+        dr.append(rng.normal(size=(360, 3)))
+    desc.add_plane((0.0, 0.0, -3.0), (0.0, 0.0, 1.0), mats[0])
+    desc.area_light((0.0, 0.0, 30.0), 3.0, (5.0, 5.0, 5.0))
+    desc.set_camera((0.0, -12.0, 3.0), (0.0, 12.0, -3.0), scenes.ASPECT_RATIO)
+    scene = rt.Scene(desc)
+    ctx.upload(scene)
+    orc = ob.OracleScene(desc)
+    org = np.concatenate(org).astype(np.float32)
+    dr = np.concatenate(dr).astype(np.float32)
+    dr = (dr / np.linalg.norm(dr, axis=1, keepdims=True)).astype(np.float32)
+
+    differs_from_unbounded = 0
+    for t_min, t_max in ((1e-3, np.inf), (0.0, 0.5), (0.2, 1.0), (0.5, 3.0), (1e-3, 1.0)):
+        o = orc.trace_closest(org, dr, t_min, t_max)
+        oa = orc.trace_any(org, dr, t_min, t_max)
+        assert (o["obj"] != rt.api.RT_MISS).sum() > 100, (t_min, t_max)
+        for counters, mode in ((False, 0), (True, rt.api.COUNT_REFERENCE), (True, rt.api.COUNT_FETCHES)):
+            ctx.set_visit_count_mode(mode)
+            g = ctx.trace_closest(org, dr, t_min, t_max, counters=counters)
+            for k in ("obj", "prim", "front_face"):
+                assert np.array_equal(g[k], o[k]), (t_min, t_max, counters, mode, k)
+            for k in ("t", "nx", "ny", "nz"):
+                assert np.array_equal(g[k].view(np.uint32), o[k].view(np.uint32)), (t_min, t_max, counters, mode, k)
+            ga = ctx.trace_any(org, dr, t_min, t_max, counters=counters)
+            assert np.array_equal(ga["occluded"], oa["occluded"]), (t_min, t_max, counters, mode)
+            if counters and mode == rt.api.COUNT_REFERENCE:
+                assert np.array_equal(g["n_int"], o["n_int"]) and np.array_equal(g["n_tri"], o["n_tri"])
+                assert np.array_equal(ga["n_int"], oa["n_int"]) and np.array_equal(ga["n_tri"], oa["n_tri"])
+            if counters and mode == rt.api.COUNT_FETCHES:  # the timed kernels fetch no more than the reference does
+                assert (g["n_int"] <= o["n_int"]).all() and (g["n_tri"] <= o["n_tri"]).all()
+                assert g["n_int"].sum() < o["n_int"].sum()
+        ctx.set_visit_count_mode(rt.api.COUNT_REFERENCE)
+        # the case the world-range cull got wrong: hits whose WORLD t lies outside (t_min, t_max)
+        hit = o["obj"] != rt.api.RT_MISS
+        differs_from_unbounded += int((hit & ((o["t"] > t_max) | (o["t"] < t_min))).sum())
+    assert differs_from_unbounded > 50

@@ -116,3 +116,26 @@ def test_config5_instances_full_resolution_subset(ctx):
                          np.random.default_rng(6).choice(W * H, 400, replace=False)]).astype(np.uint32)
     ref, _ = orc.render_pixels(W, H, px, 4, 16, 3, threads=8)
     assert np.array_equal(img.reshape(-1, 3)[px].view(np.uint32), ref.view(np.uint32))
+
+
+def test_stl_scene_full_resolution_subset(ctx):
+    """The STL-fed scene (baby_yoda.stl as Dielectric with a homogeneous medium, the subdivided 262 144-triangle
+    tetrahedron scaled x48 beside it, src/main.rs:214-299 + SURVEY.md config 3) at 1080p: pixels over the glass
+    figure, over the scaled mesh and random ones against the oracle, bit for bit."""
+    import os
+    stl = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "baby_yoda.stl")
+    desc = scenes.baby_yoda_scene(stl, sigma_s=0.05, extra_mesh_levels=8)
+    scene = rt.Scene(desc)
+    ctx.upload(scene)
+    orc = ob.OracleScene(desc)
+    img, st = ctx.render(W, H, 4, 16, 13)
+    assert np.isfinite(img).all() and img.mean() > 0
+    org, dr = scenes.pixel_center_rays(scene.flat.camera, W, H)
+    objs = ctx.trace_closest(org, dr)["obj"]
+    figure, tetra = np.flatnonzero(objs == 0), np.flatnonzero(objs == 3)
+    assert len(figure) > 100000 and len(tetra) > 10000
+    px = np.concatenate([np.random.default_rng(7).choice(figure, 600, replace=False),
+                         np.random.default_rng(8).choice(tetra, 300, replace=False),
+                         np.random.default_rng(9).choice(W * H, 300, replace=False)]).astype(np.uint32)
+    ref, _ = orc.render_pixels(W, H, px, 4, 16, 13, threads=8)
+    assert np.array_equal(img.reshape(-1, 3)[px].view(np.uint32), ref.view(np.uint32))

@@ -130,10 +130,10 @@ def test_matrix_inverse():
     inv, prod = (C.c_float * 9)(), (C.c_float * 9)()
     assert lib.orc_matrix_inverse(f9(m), inv)
     lib.orc_matrix_mul(f9(m), inv, prod)
-    # the reference asks 1e-9; its own f32 arithmetic reaches that for this triangular matrix
+    # the reference's own bound (matrix.rs:159): |M * M^-1 - I| < 1e-9 per element
     for i in range(3):
         for j in range(3):
-            assert abs(prod[3 * i + j] - (1.0 if i == j else 0.0)) <= 1e-9 or abs(prod[3 * i + j] - (1.0 if i == j else 0.0)) < 1.2e-7
+            assert abs(prod[3 * i + j] - (1.0 if i == j else 0.0)) < 1e-9
     assert not lib.orc_matrix_inverse(f9([1, 2, 3, 2, 4, 6, 0, 0, 1]), inv)  # singular -> None
 
 

@@ -6,6 +6,8 @@ the mean radiance.  Because both sides share the counter-based RNG, the operatio
 transcendental functions, the tests additionally require the radiance sums to be BIT-IDENTICAL and
 the ray counts (Engine::hit / Engine::hit_bool calls) and traversal visit counters to be equal.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -85,6 +87,26 @@ def test_config1_scene_checkered_medium(ctx):
 
 def test_primitives_scene_conductor_and_two_lights(ctx):
     _check(ctx, scenes.primitives_scene(), 96, 54, 4, 16, seed=2)
+
+
+def test_spotlight_and_point_light(ctx):
+    """Spotlight::sample (lights.rs:57-75, d2 taken of the already normalised direction) next to a PointLight:
+    shading points inside and outside the cone, uniform light pick between the two."""
+    img, st, _ = _check(ctx, scenes.spotlight_scene(levels=3), 96, 54, 4, 16, seed=21)
+    assert img.mean() > 0 and st.rays_shadow > 0
+
+
+STL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "baby_yoda.stl")
+
+
+def test_stl_fed_scene_baby_yoda(ctx):
+    """scene_baby_yoda (src/main.rs:214-299) from the reference's own asset (committed as a data fixture): binary STL
+    -> read_stl with vertex unification (stl.rs:8-143) -> BVH build -> upload -> HIP path, against the oracle, which
+    builds its own tree from the same ingested arrays.  As in the reference (sigma_s = 0), then with scattering and
+    the subdivided tetrahedron beside it (the tetrahedron is scaled x48)."""
+    img, st, _ = _check(ctx, scenes.baby_yoda_scene(STL), 96, 54, 4, 16, seed=7)
+    assert img.mean() > 0 and st.iterations > 4
+    _check(ctx, scenes.baby_yoda_scene(STL, sigma_s=0.05, extra_mesh_levels=4), 96, 54, 4, 16, seed=8)
 
 
 def test_batching_and_sample_offsets_do_not_change_the_image(ctx):
