@@ -268,6 +268,19 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
 int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max,
                  uint8_t* occluded, uint32_t* n_int, uint32_t* n_tri);
 
+/* Allocation-free form of rt_trace_closest.  NO counterpart in the reference: it exists for callers that cannot
+   call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+   results as rt_trace_closest, bit for bit, but it calls no hipMalloc / hipFree / allocating routine: the
+   launch's scratch (work counters + traversal-stack overflow strips) lives in a static device array of
+   24.008 MiB that every GPU the library runs on holds until the process ends.  Limits: every ray / hit array
+   must be DEVICE memory (no staging), n <= RT_NOALLOC_MAX_RAYS, and the scene's deepest BVH must not exceed
+   RT_NOALLOC_MAX_STACK_DEPTH levels (RT_ERR_LIMIT otherwise).  All calls on one GPU share the static array:
+   calls that overlap on the same GPU (two contexts, two threads) race; serialise them. */
+#define RT_NOALLOC_MAX_RAYS 0xFFFFFFF0ull
+#define RT_NOALLOC_MAX_STACK_DEPTH 32
+int rt_trace_closest_noalloc(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max,
+                             const rt_hits* hits);
+
 typedef struct rt_stats {
     uint64_t rays_closest;  /* Engine::hit calls issued (extend kernel lanes) */
     uint64_t rays_shadow;   /* Engine::hit_bool calls issued (shadow-connect lanes) */

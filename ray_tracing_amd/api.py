@@ -123,7 +123,7 @@ class Stats(C.Structure):
 EXPORTS = ["rt_mesh_create", "rt_mesh_read_stl", "rt_mesh_loop_subdivide", "rt_mesh_apply_transform",
            "rt_mesh_volume_centroid", "rt_mesh_counts", "rt_mesh_copy_out", "rt_mesh_destroy", "rt_scene_build",
            "rt_scene_view", "rt_scene_destroy", "rt_tonemap_u8", "rt_write_ppm", "rt_create", "rt_destroy",
-           "rt_upload_scene", "rt_initial_medium", "rt_trace_closest", "rt_trace_any", "rt_render",
+           "rt_upload_scene", "rt_initial_medium", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render",
            "rt_set_max_paths_in_flight", "rt_set_visit_count_mode", "rt_last_kernel_ms", "rt_stream", "rt_last_error", "rt_version"]
 
 if not os.path.exists(LIB_PATH):
@@ -162,6 +162,7 @@ lib.rt_mesh_destroy.restype = None
 lib.rt_scene_destroy.argtypes = [C.c_void_p]
 lib.rt_scene_destroy.restype = None
 lib.rt_trace_closest.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.c_float, C.c_float, C.POINTER(Hits)]
+lib.rt_trace_closest_noalloc.argtypes = lib.rt_trace_closest.argtypes
 lib.rt_trace_any.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                              C.c_void_p]
 lib.rt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
@@ -443,6 +444,12 @@ class Context:
         rays = Rays(*rays6)
         hits = Hits(*[hits_ptrs.get(k) for k, _ in Hits._fields_])
         _check(lib.rt_trace_closest(self.handle, C.byref(rays), n, t_min, t_max, C.byref(hits)))
+
+    def trace_closest_noalloc(self, rays6, n, hits_ptrs, t_min=1e-3, t_max=np.inf):
+        """rt_trace_closest_noalloc: device addresses only, no allocation inside the library."""
+        rays = Rays(*rays6)
+        hits = Hits(*[hits_ptrs.get(k) for k, _ in Hits._fields_])
+        _check(lib.rt_trace_closest_noalloc(self.handle, C.byref(rays), n, t_min, t_max, C.byref(hits)))
 
     def trace_any_device(self, rays6, n, occluded, t_min=1e-3, t_max=np.inf, n_int=None, n_tri=None):
         rays = Rays(*rays6)

@@ -84,6 +84,7 @@ struct rt_ctx {
     uint64_t max_paths_in_flight = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     float last_kernel_ms = 0.0f;
+    uint32_t* scratch = nullptr;  // this device's copy of the static scratch array (rt_device.hip), resolved by rt_create
     uint32_t count_mode = RT_COUNT_REFERENCE;  // what rt_trace_*'s n_int / n_tri count (rt_set_visit_count_mode)
 };
 

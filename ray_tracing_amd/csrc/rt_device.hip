@@ -137,6 +137,18 @@ __global__ RT_TRACE_ATTR_LEAN void k_trace_lean(DScene sc, TraceIO io, uint32_t 
         sc, io, n, work_counter, tune, t_min, t_max, lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
 
+// ---------------------------------------------------------------- scratch of the allocation-free entry point
+// rt_trace_closest_noalloc (include/rt_amd.h) may not call hipMalloc: the two scratch buffers of a trace launch --
+// the work counters and the traversal-stack overflow strips -- live in this file-scope device array instead.  Every
+// GPU the library runs on holds its own copy (24.008 MiB) until the process ends; the array's NAME is only a
+// host-side stand-in, so rt_create resolves its address on the context's device once (hipGetSymbolAddress) and
+// host code uses that pointer everywhere.  All calls on one GPU share the array: calls that overlap on a GPU race.
+constexpr uint32_t NOALLOC_LEVELS = RT_NOALLOC_MAX_STACK_DEPTH - RT_STACK_MIN;       // overflow levels the strips hold
+constexpr size_t NOALLOC_LANES = (size_t)RT_TRACE_GRID * RT_BLOCK;                   // lanes of the largest trace grid
+constexpr size_t SCRATCH_U32 = WORK_U32 + NOALLOC_LANES * NOALLOC_LEVELS;
+static_assert(RT_NOALLOC_MAX_STACK_DEPTH > RT_STACK_MIN, "the allocation-free entry point needs at least one overflow level");
+static __device__ __align__(256) uint32_t scratch[SCRATCH_U32];
+
 // ---------------------------------------------------------------- helpers
 namespace {
 
@@ -242,9 +254,21 @@ int rt_create(int device, rt_ctx** out) {
     RT_HIP(hipSetDevice(device));
     rt_ctx* ctx = new rt_ctx;
     ctx->device = device;
-    RT_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    RT_HIP(hipEventCreate(&ctx->ev[0]));
-    RT_HIP(hipEventCreate(&ctx->ev[1]));
+    // address of THIS device's copy of `scratch` (the device is current); never the array's name in host code
+    hipError_t es = hipGetSymbolAddress((void**)&ctx->scratch, HIP_SYMBOL(scratch));
+    if (es != hipSuccess || !ctx->scratch) {
+        rth::set_error("rt_create: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(es));
+        delete ctx;
+        return RT_ERR_HIP;
+    }
+    hipError_t ec = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (ec == hipSuccess) ec = hipEventCreate(&ctx->ev[0]);
+    if (ec == hipSuccess) ec = hipEventCreate(&ctx->ev[1]);
+    if (ec != hipSuccess) {
+        rth::set_error("rt_create: stream / event creation failed: %s", hipGetErrorString(ec));
+        rt_destroy(ctx);
+        return RT_ERR_HIP;
+    }
     *out = ctx;
     return RT_OK;
 }
@@ -675,6 +699,43 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
                            (uint32_t)lanes)) != RT_OK)
         return rc;
     if ((rc = sg.finish()) != RT_OK) return rc;
+    RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
+    return RT_OK;
+}
+
+int rt_trace_closest_noalloc(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, const rt_hits* hits) {
+    int rc = check_ctx(ctx, true);
+    if (rc != RT_OK) return rc;
+    if (rays_null(rays) || !hits || !hits->t) {
+        rth::set_error("rt_trace_closest_noalloc: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (n == 0) return RT_OK;
+    if (n > RT_NOALLOC_MAX_RAYS) {
+        rth::set_error("rt_trace_closest_noalloc: %zu rays exceed the limit of %llu per call", n,
+                       (unsigned long long)RT_NOALLOC_MAX_RAYS);
+        return RT_ERR_LIMIT;
+    }
+    if (ctx->scene.stack_need > (uint32_t)RT_NOALLOC_MAX_STACK_DEPTH) {
+        rth::set_error("rt_trace_closest_noalloc: the scene's deepest BVH (%u levels) exceeds the %d levels the static "
+                       "scratch holds; use rt_trace_closest", ctx->scene.stack_need, RT_NOALLOC_MAX_STACK_DEPTH);
+        return RT_ERR_LIMIT;
+    }
+    // staging host arrays would need device buffers: every array must already be device memory
+    const void* ptrs[] = {rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, hits->t, hits->prim, hits->obj,
+                          hits->nx, hits->ny, hits->nz, hits->front_face, hits->n_int, hits->n_tri};
+    for (const void* p : ptrs)
+        if (p && !is_device_ptr(p)) {
+            rth::set_error("rt_trace_closest_noalloc: every ray / hit array must be device memory");
+            return RT_ERR_INVALID;
+        }
+    const int grid = trace_grid(n);
+    uint32_t* work = ctx->scratch;               // [0, WORK_U32): work counters, zeroed per call
+    uint32_t* overflow = ctx->scratch + WORK_U32;  // the strips need no initial value (written before they are read)
+    RT_HIP(hipMemsetAsync(work, 0, WORK_U32 * sizeof(uint32_t), ctx->stream));
+    TraceIO io{*rays, *hits, nullptr};
+    if ((rc = launch_trace(ctx, false, io, n, t_min, t_max, grid, work, overflow, (uint32_t)NOALLOC_LANES)) != RT_OK) return rc;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
     RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
     return RT_OK;
 }
