@@ -5,9 +5,14 @@
 
 workload "render" (default): BASELINE.json configs[2] -- full path tracing (diffuse/dielectric BSDFs,
     area-light NEE/MIS, Russian roulette) of the 1M-triangle scene at 1920x1080, 64 spp, depth 16.
-    One step = one frame.  With N GPUs every rank renders its own 64 global sample indices
-    [rank*64, rank*64+64) of the same frame and the radiance accumulators are summed to rank 0 with
-    one RCCL reduce over xGMI (weak scaling: the frame gains samples, per-GPU work is fixed).
+    One step = one frame.  With N GPUs the 64 samples of the frame are sharded by global sample index
+    (rank r renders sample_shard(64, N, r) of every pixel) and the radiance accumulators are summed to
+    rank 0 with one RCCL reduce over xGMI through the C ABI (rt_reduce_accum), inside the timed region:
+    STRONG scaling, the BASELINE metric "ms/frame @1080p 64 spp at 1/2/4/8 GPUs".  --scaling weak gives
+    every rank its own 64 samples instead (the frame gains samples).
+workload "config5": BASELINE.json configs[4]'s scene -- a plane and 10 subdivided tetrahedra, each its OWN
+    mesh and BVH (10.5 M triangles, 1.1 GB of geometry: beyond the 256 MiB Infinity Cache); --instanced
+    shares one BVH instead.  --width 3840 for 4K.  Used for the cache-resident / out-of-cache comparison.
 workload "trace": BASELINE.json configs[1] -- primary + shadow rays only, same mesh, 1080p 1 spp.
     One step = one closest-hit launch over 2 073 600 primary rays + one any-hit launch over the
     shadow rays of the pixels that hit.
@@ -31,6 +36,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# Vector-L1 return path: 256 CUs x 64 B/clk x 2.4 GHz (a 64-lane dwordx4 load occupies the texture-data path for 16
+# cycles, profiles/r01/tuning.md section 12).  The ceiling of per-lane record gathers that hit on chip.
+L1_PEAK_GBS = 256 * 64 * 2.4
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: L2 aggregate
 
 
 def parse():
@@ -38,7 +47,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["render", "trace"], default="render")
+    ap.add_argument("--workload", choices=["render", "trace", "config5"], default="render")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--instanced", action="store_true", help="config5: ten instances of ONE mesh/BVH instead of ten meshes")
+    ap.add_argument("--copies", type=int, default=10)
+    ap.add_argument("--torch-reduce", action="store_true", help="N>1: reduce with torch.distributed instead of rt_reduce_accum")
     ap.add_argument("--levels", type=int, default=9, help="Loop subdivisions of the tetrahedron (9 = 1 048 576 tris)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--spp", type=int, default=64)
@@ -79,6 +92,8 @@ def main():
     t_setup = time.time()
     if args.workload == "trace":
         desc = scenes.tetrahedron_scene(levels=args.levels)
+    elif args.workload == "config5":
+        desc = scenes.multi_mesh_scene(levels=args.levels, copies=args.copies, distinct=not args.instanced)
     else:
         desc = scenes.path_scene(levels=args.levels)
     scene = rt.Scene(desc)
@@ -102,7 +117,8 @@ def main():
         torch.cuda.synchronize()
         rays6 = [c.data_ptr() for c in cols]
         hp = dict(t=t.data_ptr(), prim=prim.data_ptr(), obj=obj.data_ptr())
-        # untimed counting pass: visit counters for the algorithmic-bytes figure + shadow-ray set-up
+        # untimed counting pass: the timed kernel's own fetches for the algorithmic-bytes figure + shadow-ray set-up
+        ctx.set_visit_count_mode(rt.api.COUNT_FETCHES)
         ctx.trace_closest_device(rays6, n, dict(hp, n_int=ni.data_ptr(), n_tri=nt.data_ptr()))
         n_int_total, n_tri_total = int(ni.sum().item()), int(nt.sum().item())
         hit = obj != -1
@@ -143,21 +159,51 @@ def main():
                       rays_closest=n, rays_shadow=ns)
         workload = f"configs[1]: primary+shadow rays, {n_tris}-triangle subdivided tetrahedron, {width}x{height}, 1 spp"
     else:
+        from ray_tracing_amd.distributed import sample_shard
         acc = torch.zeros(height, width, 3, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
-        spp_first = rank * args.spp
-        # untimed counting pass (also the warm-up of every kernel)
-        _, st_count = ctx.render(width, height, args.spp, args.depth, args.seed, spp_first,
-                                 flags=rt.api.RENDER_COUNT_VISITS, out=acc.data_ptr())
+        if args.scaling == "strong":  # the 64-spp frame, sharded by global sample index
+            spp_first, spp_count = sample_shard(args.spp, world, rank)
+        else:                          # every rank its own args.spp samples
+            spp_first, spp_count = rank * args.spp, args.spp
+        # the accumulator reduce: RCCL through the C ABI on the library's own stream (ordered behind rt_render
+        # without a host sync); torch.distributed only carries the unique id and the barriers
+        comm, reduce_kind = None, "none"
+        if use_dist:
+            reduce_kind = "torch.distributed"
+            if not args.torch_reduce:
+                try:
+                    uid = torch.zeros(rt.api.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+                    if rank == 0:
+                        uid = torch.tensor(list(rt.comm_unique_id()), dtype=torch.uint8, device=dev)
+                    dist.broadcast(uid, src=0)
+                    comm = rt.Comm(ctx, bytes(uid.cpu().tolist()), world, rank)
+                    reduce_kind = "rt_reduce_accum (RCCL, C ABI)"
+                except rt.RtError as e:  # plumbing fallback for the collective only; labelled in the output
+                    print(f"bench: rt_comm_create failed on rank {rank} ({e}); reducing with torch.distributed", file=sys.stderr)
+            ok = torch.tensor([1 if (comm is not None or args.torch_reduce) else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:  # some rank fell back: all ranks must
+                comm.close()
+                comm, reduce_kind = None, "torch.distributed"
+        # untimed counting passes (also the warm-up of every kernel): the fetches the timed kernels perform
+        # (root-box skip and top-level cull active) price the roofline; the reference's visits are listed beside
+        _, st_count = ctx.render(width, height, spp_count, args.depth, args.seed, spp_first,
+                                 flags=rt.api.RENDER_COUNT_FETCHES, out=acc.data_ptr())
+        _, st_ref = ctx.render(width, height, spp_count, args.depth, args.seed, spp_first,
+                               flags=rt.api.RENDER_COUNT_VISITS, out=acc.data_ptr())
         last = {}
 
         ext_ms, ext_launches, mix_ms, mix_launches = [], [], [], []
 
         def step(record, all_stages=False):
-            _, st = ctx.render(width, height, args.spp, args.depth, args.seed, spp_first,
+            _, st = ctx.render(width, height, spp_count, args.depth, args.seed, spp_first,
                                flags=rt.api.RENDER_TIME_STAGES if all_stages else 0, out=acc.data_ptr())
-            if use_dist:
+            if comm is not None:
+                comm.reduce_accum(acc.data_ptr(), width, height, 0)  # returns when the sum is complete
+            elif use_dist:
                 dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()  # the next render overwrites acc on the library's stream
             last["st"] = st
             if record:  # k_extend is timed by HIP events on the library's stream in every render call
                 ext_ms.append(st.ms_extend)
@@ -177,42 +223,53 @@ def main():
         step(False, all_stages=True)
         st = last["st"]
         rays_per_step = st.rays_closest + st.rays_shadow
-        # algorithmic bytes of the rays k_extend traced (the tail kernel's share, if any, is not its work)
-        alg_bytes_total = (48 * (st_count.rays_closest - st_count.rays_closest_tail)
-                           + 64 * (st_count.nodes_visited - st_count.nodes_visited_tail)
-                           + 40 * (st_count.tris_tested - st_count.tris_tested_tail))
+
+        def alg_bytes(c, ext):  # 48 + 64 N_int + 40 N_tri per ray of the extend / of the mixed+tail launches
+            if ext:
+                return (48 * (c.rays_closest - c.rays_closest_tail) + 64 * (c.nodes_visited - c.nodes_visited_tail)
+                        + 40 * (c.tris_tested - c.tris_tested_tail))
+            return (48 * (c.rays_closest_tail + c.rays_shadow_tail) + 64 * (c.nodes_visited_tail + c.nodes_visited_shadow_tail)
+                    + 40 * (c.tris_tested_tail + c.tris_tested_shadow_tail))
+
         launches = max(1, int(np.mean(ext_launches)))
         ms_extend_timed = float(np.mean(ext_ms))  # average over the K timed frames
-        # The same traversal loop also runs in the mixed launches (shadow rays of bounce k + rays of bounce k+1):
-        # their algorithmic bytes are those of both kinds of ray they traced.
-        mix_bytes_total = (48 * (st_count.rays_closest_tail + st_count.rays_shadow_tail)
-                           + 64 * (st_count.nodes_visited_tail + st_count.nodes_visited_shadow_tail)
-                           + 40 * (st_count.tris_tested_tail + st_count.tris_tested_shadow_tail))
         n_mix = max(1, int(np.mean(mix_launches)))
         ms_mix_timed = float(np.mean(mix_ms))
         lean_sfx = "_lean" if st.lean_kernels else ""
         kernels = {
-            "k_extend" + lean_sfx: {"kernel_ms": ms_extend_timed / launches, "alg_bytes": alg_bytes_total / launches,
+            "k_extend" + lean_sfx: {"kernel_ms": ms_extend_timed / launches, "alg_bytes": alg_bytes(st_count, True) / launches,
+                                    "ref_bytes": alg_bytes(st_ref, True) / launches,
                                     "launches": int(launches), "ms_per_frame": ms_extend_timed},
-            "k_mixed" + lean_sfx: {"kernel_ms": ms_mix_timed / n_mix, "alg_bytes": mix_bytes_total / n_mix,
+            "k_mixed" + lean_sfx: {"kernel_ms": ms_mix_timed / n_mix, "alg_bytes": alg_bytes(st_count, False) / n_mix,
+                                   "ref_bytes": alg_bytes(st_ref, False) / n_mix,
                                    "launches": int(n_mix), "ms_per_frame": ms_mix_timed},
         }
-        # `roofline` prices the closest-hit kernel of the largest launches; the mixed launches are listed beside it
-        result["kernels"] = {k: {"achieved_GBs": round(v["alg_bytes"] / (v["kernel_ms"] * 1e-3) / 1e9, 1) if v["kernel_ms"] > 0 else None,
-                                 "frac": round(v["alg_bytes"] / (v["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v["kernel_ms"] > 0 else None,
+        gbs = lambda v, key="alg_bytes": v[key] / (v["kernel_ms"] * 1e-3) / 1e9 if v["kernel_ms"] > 0 else None
+        result["kernels"] = {k: {"fetched_GBs": round(gbs(v), 1) if gbs(v) else None,
+                                 "reference_visit_GBs": round(gbs(v, "ref_bytes"), 1) if gbs(v) else None,
                                  "launches": v["launches"], "ms_per_launch": round(v["kernel_ms"], 4),
-                                 "ms_per_frame": round(v["ms_per_frame"], 3), "alg_bytes_per_launch": int(v["alg_bytes"])}
+                                 "ms_per_frame": round(v["ms_per_frame"], 3), "alg_bytes_per_launch": int(v["alg_bytes"]),
+                                 "reference_visit_bytes_per_launch": int(v["ref_bytes"])}
                              for k, v in kernels.items()}
-        result.update(kernel="k_extend" + lean_sfx, kernel_ms=ms_extend_timed / launches, alg_bytes=alg_bytes_total / launches,
+        ext = kernels["k_extend" + lean_sfx]
+        result.update(kernel="k_extend" + lean_sfx, kernel_ms=ext["kernel_ms"], alg_bytes=ext["alg_bytes"],
                       launches=int(launches), ms_extend=ms_extend_timed, ms_shadow=st.ms_shadow, ms_shade=st.ms_shade,
                       ms_generate=st.ms_generate, ms_compact=st.ms_compact, ms_tail=st.ms_tail,
                       paths_tail=int(st.paths_tail), ms_device_total=st.ms_total,
                       n_int_mean=st_count.nodes_visited / max(1, st_count.rays_closest),
                       n_tri_mean=st_count.tris_tested / max(1, st_count.rays_closest),
+                      n_int_reference=st_ref.nodes_visited / max(1, st_ref.rays_closest),
                       rays_closest=int(st.rays_closest), rays_shadow=int(st.rays_shadow),
-                      iterations=int(st.iterations))
-        workload = (f"configs[2]: path tracing diffuse+dielectric, area-light NEE/MIS, RR, {n_tris} triangles, "
-                    f"{width}x{height}, {args.spp} spp, depth {args.depth}")
+                      iterations=int(st.iterations), spp_this_rank=int(spp_count), reduce=reduce_kind)
+        if args.workload == "config5":
+            workload = (f"configs[4] scene: plane + {args.copies} subdivided tetrahedra, "
+                        f"{'instances of one BVH' if args.instanced else 'each its own mesh and BVH'}, {n_tris} triangles, "
+                        f"{width}x{height}, {args.spp} spp, depth {args.depth}")
+        else:
+            workload = (f"configs[2]: path tracing diffuse+dielectric, area-light NEE/MIS, RR, {n_tris} triangles, "
+                        f"{width}x{height}, {args.spp} spp, depth {args.depth}")
+        if comm is not None:
+            comm.close()
 
     # max over ranks of the timed region
     if use_dist:
@@ -227,22 +284,48 @@ def main():
 
     if rank == 0:
         stream_copy = stream_copy_gbs(torch, dev)
-        traffic, traffic_detail = committed_traffic(args, result["kernel"])
+        traffic, traffic_detail = committed_traffic(args, result["kernel"], rt.api.build_id(), world)
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays_per_step * args.steps / elapsed / 1e6
         achieved = result["alg_bytes"] / (result["kernel_ms"] * 1e-3) / 1e9
+        # Which ceiling binds.  The algorithmic bytes are what the lanes REQUEST (64 B per node visit, 40 B per triangle
+        # test); the vector L1 and L2 serve most of them, so only where the memory-side counters show
+        # that most requested bytes reach the fabric is HBM the bound.  Without a counter profile of this build: by
+        # the geometry's size against the 256 MiB Infinity Cache.
+        geom_bytes = scene.flat.n_tris * 48 + max(0, scene.flat.n_nodes - scene.flat.n_bvhs) * 32
+        if traffic is not None:
+            hbm_bound = traffic >= 0.5 * result["alg_bytes"]
+        else:
+            hbm_bound = geom_bytes > (256 << 20)
+        peak = HBM_PEAK_GBS if hbm_bound else L1_PEAK_GBS
+        levels = {"l1_return_path": {"achieved_GBs": round(achieved, 1), "peak_GBs": round(L1_PEAK_GBS, 1),
+                                     "frac": round(achieved / L1_PEAK_GBS, 4), "bytes": "algorithmic (requested by the lanes)"}}
+        if traffic is not None:
+            t_gbs = traffic / (result["kernel_ms"] * 1e-3) / 1e9
+            levels["memory_side"] = {"achieved_GBs": round(t_gbs, 1), "peak_GBs": HBM_PEAK_GBS, "frac": round(t_gbs / HBM_PEAK_GBS, 4),
+                                     "frac_of_stream_copy": round(t_gbs / stream_copy, 4),
+                                     "bytes": "FETCH_SIZE x2 + WRITE_SIZE (fabric side of L2: Infinity Cache + HBM)"}
         out = {
             "metric": "Mrays/s (path-segment rays, whole node)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "seed": args.seed, "parallelism": f"sample-sharded x{world}" if world > 1 else "1 GPU",
-                       "ms_per_frame": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, committed profile)", "traffic_detail": traffic_detail,
+            "higher_is_better": True, "scaling": args.scaling if args.workload != "trace" else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "seed": args.seed,
+                       "parallelism": (f"sample-sharded x{world} ({args.scaling}), {result.get('reduce', 'none')}" if world > 1 else "1 GPU"),
+                       "ms_per_frame": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1),
+                       "geometry_bytes": int(geom_bytes), "build": rt.api.build_id()},
+            "roofline": {"bound": "hbm" if hbm_bound else "l1", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "bound_note": ("most requested bytes reach the memory side: HBM 8 TB/s binds" if hbm_bound else
+                                        "the geometry is served on chip (traffic << algorithmic bytes): the binding ceiling is the "
+                                        "vector-L1 return path, 256 CUs x 64 B/clk x 2.4 GHz; `levels.memory_side` gives the HBM-side fraction"),
+                         "levels": levels,
+                         "traffic_unit": "bytes per launch (PMC, committed profile of this build)", "traffic_detail": traffic_detail,
                          "stream_copy_GBs": round(stream_copy, 1),
                          "kernel": result["kernel"], "kernel_ms": round(result["kernel_ms"], 4),
                          "alg_bytes_per_launch": int(result["alg_bytes"]),
+                         "alg_bytes_note": "48 + 64 N_int + 40 N_tri per ray with N_int / N_tri counted on the TIMED kernel's own fetches "
+                                           "(root-box skip and top-level cull active)",
                          "n_int_per_ray": round(result["n_int_mean"], 3), "n_tri_per_ray": round(result["n_tri_mean"], 3),
                          **({"traversal_kernels": result["kernels"]} if "kernels" in result else {})},
             "detail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in result.items()
@@ -272,23 +355,29 @@ def stream_copy_gbs(torch, dev):
     return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def committed_traffic(args, kernel):
-    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes committed under profiles/
-    (scripts/pmc_traffic.sh; counters cannot be read from inside this process).  None unless a
-    committed measurement exists for exactly this workload."""
+def committed_traffic(args, kernel, build, world):
+    """Memory-side bytes per launch of `kernel` from the rocprofv3 --pmc passes committed under profiles/
+    (scripts/pmc_traffic.sh; counters cannot be read from inside this process).  None unless a committed
+    measurement exists for exactly this workload AND this build of the library (a profile of other code says
+    nothing about this run)."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "final", "pmc_traffic.json")), reverse=True):
+    if world != 1:
+        return None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "**", "pmc_traffic*.json"), recursive=True), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
         w = d.get("workload", {})
+        if d.get("build") != build:
+            continue
         if (w.get("name") == args.workload and w.get("levels") == args.levels and w.get("width") == args.width
-                and w.get("spp") == args.spp and w.get("depth") == args.depth and kernel in d.get("kernels", {})):
+                and w.get("spp") == args.spp and w.get("depth") == args.depth
+                and w.get("instanced", False) == bool(getattr(args, "instanced", False)) and kernel in d.get("kernels", {})):
             k = d["kernels"][kernel]
             return k["hbm_bytes_per_launch"], {"fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
                                                "launches": k["launches"], "l2_hit_rate": k.get("l2_hit_rate"),
-                                               "source": os.path.relpath(f, ROOT), "note": d.get("note", "")}
+                                               "source": os.path.relpath(f, ROOT), "build": d.get("build"), "note": d.get("note", "")}
     return None, None
 
 
@@ -316,9 +405,10 @@ def cpu_baseline(args, desc, scene, width, height):
         rays = len(o) + len(p)
         return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
                 "sample": f"every 4th image row of the same ray batch ({rays} rays, {dt:.1f} s)"}
-    # bounded sample: 7 bands of 8 image rows spread over the frame, at the full spp (about 7 M camera
-    # paths, 10-30 s on one core); the same sample again on all host cores
-    bands = [(int(height * (k + 0.5) / 7) - 4, int(height * (k + 0.5) / 7) + 4) for k in range(7)]
+    # bounded sample: 2 bands of 8 image rows (a third and two thirds up the frame) at the full spp -- about 2 M
+    # camera paths, ~3 s on one core -- so that the GPU region stays a visible share of the run; the same sample
+    # again on all host cores
+    bands = [(int(height * (k + 1) / 3) - 4, int(height * (k + 1) / 3) + 4) for k in range(2)]
 
     pixels = np.concatenate([np.arange(r0 * width, r1 * width, dtype=np.uint32) for r0, r1 in bands])
 
@@ -330,7 +420,7 @@ def cpu_baseline(args, desc, scene, width, height):
     ncores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     rays_all, secs_all = run(ncores)
     return {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"56 image rows (7 bands of 8) of the same frame at {args.spp} spp ({rays} rays, {secs:.1f} s); "
+            "sample": f"16 image rows (2 bands of 8) of the same frame at {args.spp} spp ({rays} rays, {secs:.1f} s); "
                       "1 thread = the reference's own execution model",
             "all_cores": {"value": round(rays_all / secs_all / 1e6, 4), "unit": "Mrays/s", "cores": ncores,
                           "seconds": round(secs_all, 1)}}

@@ -322,6 +322,23 @@ typedef struct rt_stats {
 int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp_first, uint32_t spp_count,
               uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats);
 
+/* ---- multi-GPU (no counterpart in the reference, which is one thread: path_integrator.rs:286-308).
+   One process per GPU.  Rank r renders global samples [first_r, first_r + count_r) of every pixel into its own
+   device accumulator (rt_render's spp_first / spp_count; the random numbers are keyed by the GLOBAL sample
+   index, so the union over ranks is the single-GPU frame) and the accumulators are summed with one RCCL
+   reduce over xGMI.  RCCL (librccl.so.1) is bound at run time; without it these calls return RT_ERR_STATE. */
+typedef struct rt_comm rt_comm;
+#define RT_COMM_ID_BYTES 128
+/* ncclGetUniqueId: called on ONE rank; the host hands the bytes to every other rank (file, MPI, ...). */
+int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
+/* ncclCommInitRank on ctx's device; collective over all world_size ranks. */
+int rt_comm_create(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], int world_size, int rank, rt_comm** out);
+void rt_comm_destroy(rt_comm* comm);
+/* Sum of the ranks' rgb_sum[height][width][3] (DEVICE memory, in place) onto rank `root` (ncclReduce), or onto
+   every rank when root < 0 (ncclAllReduce).  Enqueued on the context's stream, i.e. behind the rt_render call
+   that filled rgb_sum; returns when the result is complete.  24.9 MB at 1080p, 99.5 MB at 4K. */
+int rt_reduce_accum(rt_comm* comm, float* rgb_sum, uint32_t width, uint32_t height, int root);
+
 /* Upper bound on camera paths kept in flight by rt_render (default: sized from free HBM). */
 int rt_set_max_paths_in_flight(rt_ctx* ctx, uint64_t max_paths);
 

@@ -124,6 +124,7 @@ EXPORTS = ["rt_mesh_create", "rt_mesh_read_stl", "rt_mesh_loop_subdivide", "rt_m
            "rt_mesh_volume_centroid", "rt_mesh_counts", "rt_mesh_copy_out", "rt_mesh_destroy", "rt_scene_build",
            "rt_scene_view", "rt_scene_destroy", "rt_tonemap_u8", "rt_write_ppm", "rt_create", "rt_destroy",
            "rt_upload_scene", "rt_initial_medium", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render",
+           "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy", "rt_reduce_accum",
            "rt_set_max_paths_in_flight", "rt_set_visit_count_mode", "rt_last_kernel_ms", "rt_stream", "rt_last_error", "rt_version"]
 
 if not os.path.exists(LIB_PATH):
@@ -167,6 +168,11 @@ lib.rt_trace_any.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.c_float,
                              C.c_void_p]
 lib.rt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                           C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+lib.rt_comm_unique_id.argtypes = [C.c_void_p]
+lib.rt_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+lib.rt_comm_destroy.argtypes = [C.c_void_p]
+lib.rt_comm_destroy.restype = None
+lib.rt_reduce_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
 lib.rt_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneFlat)]
 lib.rt_set_max_paths_in_flight.argtypes = [C.c_void_p, C.c_uint64]
 lib.rt_set_visit_count_mode.argtypes = [C.c_void_p, C.c_uint32]
@@ -471,6 +477,49 @@ class Context:
 
     def __del__(self):
         self.close()
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """rt_comm_unique_id: 128 bytes created on ONE rank; hand them to every rank, then Comm(ctx, id, world, rank)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib.rt_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of one rank (one process per GPU), bound to a Context's device and stream."""
+
+    def __init__(self, ctx, unique_id, world_size, rank):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._ctx = ctx  # the communicator uses the context's stream: keep it alive
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib.rt_comm_create(ctx.handle, buf, world_size, rank, C.byref(h)))
+        self.handle = h
+
+    def reduce_accum(self, rgb_sum, width, height, root=0):
+        """Sum the ranks' device accumulators in place onto `root` (root < 0: onto every rank)."""
+        _check(lib.rt_reduce_accum(self.handle, _ptr(rgb_sum), width, height, root))
+
+    def close(self):
+        if getattr(self, "handle", None) and lib is not None:
+            lib.rt_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+def version():
+    return lib.rt_version().decode()
+
+
+def build_id():
+    """Hash of the sources the loaded library was built from (last word of rt_version())."""
+    return version().split()[-1]
 
 
 def tonemap_u8(rgb_sum, spp):

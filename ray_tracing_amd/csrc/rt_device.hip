@@ -767,6 +767,9 @@ int rt_last_kernel_ms(rt_ctx* ctx, float* ms) {
     return RT_OK;
 }
 
-const char* rt_version(void) { return "ray_tracing_amd 0.1 (gfx950)"; }
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char* rt_version(void) { return "ray_tracing_amd 0.2 (gfx950) build " RT_BUILD_ID; }
 
 }  // extern "C"

@@ -90,15 +90,42 @@ def path_scene(levels=9, glass_levels=6, medium=False, sigma_s=0.02):
     return s
 
 
-def multi_mesh_scene(levels=9, copies=10):
-    """Config 5: `copies` instances of the subdivided tetrahedron, each its own Object with a
-    translation (pattern of src/main.rs:149-159), over a ground plane under a sphere area light."""
+def _rotation_xyz(ax, ay, az):
+    cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return (rz @ ry @ rx).astype(np.float32)
+
+
+def distinct_tetrahedron_mesh(levels, i):
+    """Copy i of the subdivided tetrahedron as a mesh of its OWN: vertices rotated and stretched per copy, so that
+    TriangleMesh::build_bvh gives every copy a different tree (src/main.rs:149-159 builds one mesh and one BVH per
+    object).  Copy 0 is the plain mesh."""
+    key = ("distinct", levels, i)
+    if key not in _mesh_cache:
+        v, t = tetrahedron_mesh(levels).arrays()
+        m = Mesh.from_arrays(v, t)
+        if i:
+            rot = _rotation_xyz(0.37 * i, 0.61 * i, 0.23 * i)
+            stretch = np.diag([1.0 + 0.02 * (i % 3), 1.0 - 0.015 * (i % 4), 1.0 + 0.01 * (i % 5)]).astype(np.float32)
+            m.apply_transform((rot @ stretch).astype(np.float32), (0.0, 0.0, 0.0))
+        _mesh_cache[key] = m
+    return _mesh_cache[key]
+
+
+def multi_mesh_scene(levels=9, copies=10, distinct=False):
+    """Config 5: `copies` subdivided tetrahedra, each its own Object with a translation (pattern of
+    src/main.rs:149-159), over a ground plane under a sphere area light.  distinct=False: instances of ONE mesh
+    and BVH (device geometry stays one mesh's size); distinct=True: every object has its own mesh and its own
+    BVH, as the reference builds them -- 10 x 1 048 576 triangles = 1.1 GB of child pairs and triangles, beyond
+    the 256 MiB Infinity Cache."""
     s = SceneDescription()
     grey = s.diffuse((0.8, 0.8, 0.8))
     glass = s.dielectric(1.5)
     s.add_plane((0.0, 0.0, -0.32), (0.0, 0.0, 1.0), grey)
-    mesh = tetrahedron_mesh(levels)
     for i in range(copies):
+        mesh = distinct_tetrahedron_mesh(levels, i) if distinct else tetrahedron_mesh(levels)
         col = s.diffuse((0.3 + 0.07 * (i % 10), 0.5, 1.0 - 0.07 * (i % 10)))
         s.add_mesh(mesh, glass if i % 5 == 4 else col,
                    transform=(IDENTITY, (0.0, 0.65 * (i - (copies - 1) * 0.5), 0.0)))

@@ -50,6 +50,17 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
         rt.Context(0)
 
 
+def test_comm_entry_points_report_errors_without_a_gpu():
+    """rt_comm_* validate their arguments and never abort; RCCL itself is bound at run time."""
+    import ray_tracing_amd.api as api
+    lib = ctypes.CDLL(api.LIB_PATH)
+    out = ctypes.c_void_p()
+    buf = (ctypes.c_uint8 * api.COMM_ID_BYTES)()
+    assert lib.rt_comm_create(None, buf, 2, 0, ctypes.byref(out)) == -1
+    assert lib.rt_reduce_accum(None, None, 4, 4, 0) == -1
+    lib.rt_comm_destroy(None)
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "ray_tracing_amd")
     for dirpath, _, files in os.walk(pkg):
