@@ -9,6 +9,7 @@
 
 namespace rth {
 void set_error(const char* fmt, ...);
+int on_exception(const char* who) noexcept;  // host/mesh.cpp: maps the exception in flight to a status code
 }
 
 #define RT_HIP(expr)                                                                            \

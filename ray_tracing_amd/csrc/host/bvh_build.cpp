@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 #include "host_internal.h"
@@ -217,10 +219,28 @@ unsigned build_threads() {  // RT_BUILD_THREADS, else OMP_NUM_THREADS, else the 
 
 template <class F>
 void parallel_for(unsigned n_threads, F&& f) {  // f(thread index) on n_threads threads
+    // An exception in a worker (std::bad_alloc of a large build) must not reach std::terminate: every thread is
+    // joined, then the first exception is rethrown on the calling thread, where the C ABI maps it to a status.
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back([&f, t] { f(t); });
-    f(0);
+    std::exception_ptr first;
+    std::mutex m;
+    auto run = [&](unsigned t) {
+        try {
+            f(t);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(m);
+            if (!first) first = std::current_exception();
+        }
+    };
+    try {
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back([&run, t] { run(t); });
+    } catch (...) {  // thread creation failed: the part not started runs here
+        std::lock_guard<std::mutex> g(m);
+        if (!first) first = std::current_exception();
+    }
+    run(0);
     for (auto& th : pool) th.join();
+    if (first) std::rethrow_exception(first);
 }
 
 struct Upper {  // a node of the upper tree

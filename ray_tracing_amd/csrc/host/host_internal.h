@@ -19,6 +19,9 @@ namespace rth {
 // rt_last_error() storage (thread local).
 void set_error(const char* fmt, ...);
 const char* get_error();
+// Called from the catch (...) clause of an extern "C" entry point: nothing may unwind across the C ABI.
+// std::bad_alloc -> RT_ERR_NOMEM, anything else -> RT_ERR_INVALID; the text goes to rt_last_error().
+int on_exception(const char* who) noexcept;
 
 struct BuiltBvh {  // BoundingVolumeHierarchy<TriangleRef> after build (bvh.rs:31-35)
     std::vector<Box> node_box;

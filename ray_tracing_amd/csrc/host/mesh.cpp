@@ -6,6 +6,9 @@
 #include <cstring>
 #include <unordered_map>
 
+#include <exception>
+#include <new>
+
 #include "host_internal.h"
 
 using namespace rth;
@@ -21,6 +24,20 @@ void set_error(const char* fmt, ...) {
     g_error = buf;
 }
 const char* get_error() { return g_error.c_str(); }
+int on_exception(const char* who) noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory", who);
+        return RT_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error("%s: %s", who, e.what());
+        return RT_ERR_INVALID;
+    } catch (...) {
+        set_error("%s: unknown exception", who);
+        return RT_ERR_INVALID;
+    }
+}
 }  // namespace rth
 
 namespace {
@@ -286,7 +303,7 @@ struct KeyHash {
 extern "C" {
 
 int rt_mesh_create(const float* vertices, uint32_t n_vertices, const uint32_t* triangles,
-                   uint32_t n_triangles, rt_mesh** out) {
+                   uint32_t n_triangles, rt_mesh** out) try {
     if (!out || (!vertices && n_vertices) || (!triangles && n_triangles)) {
         set_error("rt_mesh_create: null argument");
         return RT_ERR_INVALID;
@@ -304,12 +321,14 @@ int rt_mesh_create(const float* vertices, uint32_t n_vertices, const uint32_t* t
     m->triangles.assign(triangles, triangles + (size_t)n_triangles * 3);
     *out = m;
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_mesh_create");
 }
 
 // stl.rs:8-143.  80-byte header, u32 count, per triangle: normal (ignored), 3 vertices, u16
 // attribute; trailing bytes are an error (:89-99); vertices unified on their bit patterns in
 // first-seen order (:114-143).
-int rt_mesh_read_stl(const char* path, rt_mesh** out) {
+int rt_mesh_read_stl(const char* path, rt_mesh** out) try {
     if (!path || !out) {
         set_error("rt_mesh_read_stl: null argument");
         return RT_ERR_INVALID;
@@ -327,6 +346,20 @@ int rt_mesh_read_stl(const char* path, rt_mesh** out) {
     }
     uint32_t n;
     memcpy(&n, header + 80, 4);  // little-endian host
+    // the count comes from an untrusted header: check it against the file's size before reserving anything
+    long here = ftell(f), size = -1;
+    if (here >= 0 && fseek(f, 0, SEEK_END) == 0) size = ftell(f);
+    if (here < 0 || size < 0 || fseek(f, here, SEEK_SET) != 0) {
+        fclose(f);
+        set_error("rt_mesh_read_stl: %s: cannot determine the file size", path);
+        return RT_ERR_IO;
+    }
+    if ((uint64_t)(size - 84) / 50 < n) {
+        fclose(f);
+        set_error("rt_mesh_read_stl: %s: truncated (header announces %u triangles, the file holds %llu)", path, n,
+                  (unsigned long long)((size - 84) / 50));
+        return RT_ERR_IO;
+    }
     rt_mesh* m = new rt_mesh;
     m->triangles.reserve((size_t)n * 3);
     m->vertices.reserve(n / 2);
@@ -366,9 +399,11 @@ int rt_mesh_read_stl(const char* path, rt_mesh** out) {
     fclose(f);
     *out = m;
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_mesh_read_stl");
 }
 
-int rt_mesh_loop_subdivide(const rt_mesh* mesh, uint32_t divisions, rt_mesh** out) {
+int rt_mesh_loop_subdivide(const rt_mesh* mesh, uint32_t divisions, rt_mesh** out) try {
     if (!mesh || !out) {
         set_error("rt_mesh_loop_subdivide: null argument");
         return RT_ERR_INVALID;
@@ -388,6 +423,8 @@ int rt_mesh_loop_subdivide(const rt_mesh* mesh, uint32_t divisions, rt_mesh** ou
         for (int k = 0; k < 3; ++k) m->triangles.push_back(f.vertices[k]);
     *out = m;
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_mesh_loop_subdivide");
 }
 
 int rt_mesh_apply_transform(rt_mesh* mesh, const float matrix[9], const float translation[3]) {
@@ -435,7 +472,7 @@ int rt_mesh_counts(const rt_mesh* mesh, uint32_t* n_vertices, uint32_t* n_triang
     return RT_OK;
 }
 
-int rt_mesh_copy_out(const rt_mesh* mesh, float* vertices, uint32_t* triangles) {
+int rt_mesh_copy_out(const rt_mesh* mesh, float* vertices, uint32_t* triangles) try {
     if (!mesh) {
         set_error("rt_mesh_copy_out: null mesh");
         return RT_ERR_INVALID;
@@ -444,6 +481,8 @@ int rt_mesh_copy_out(const rt_mesh* mesh, float* vertices, uint32_t* triangles) 
     if (triangles)
         memcpy(triangles, mesh->triangles.data(), mesh->triangles.size() * sizeof(uint32_t));
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_mesh_copy_out");
 }
 
 void rt_mesh_destroy(rt_mesh* mesh) { delete mesh; }

@@ -95,7 +95,7 @@ int append_bvh(rt_scene* s, const rt_mesh& mesh) {
 
 extern "C" {
 
-int rt_scene_build(const rt_scene_desc* desc, rt_scene** out) {
+int rt_scene_build(const rt_scene_desc* desc, rt_scene** out) try {
     if (!desc || !out) {
         set_error("rt_scene_build: null argument");
         return RT_ERR_INVALID;
@@ -202,9 +202,11 @@ int rt_scene_build(const rt_scene_desc* desc, rt_scene** out) {
     s->initial_medium = desc->initial_medium;
     *out = s;
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_scene_build");
 }
 
-int rt_scene_view(const rt_scene* s, rt_scene_flat* out) {
+int rt_scene_view(const rt_scene* s, rt_scene_flat* out) try {
     if (!s || !out) {
         set_error("rt_scene_view: null argument");
         return RT_ERR_INVALID;
@@ -232,12 +234,14 @@ int rt_scene_view(const rt_scene* s, rt_scene_flat* out) {
     out->camera = s->camera;
     out->initial_medium = s->initial_medium;
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_scene_view");
 }
 
 void rt_scene_destroy(rt_scene* scene) { delete scene; }
 
 // path_integrator.rs:19-27 and :309-312
-int rt_tonemap_u8(const float* rgb_sum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* out) {
+int rt_tonemap_u8(const float* rgb_sum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* out) try {
     if (!rgb_sum || !out || spp == 0) {
         set_error("rt_tonemap_u8: bad argument");
         return RT_ERR_INVALID;
@@ -262,9 +266,11 @@ int rt_tonemap_u8(const float* rgb_sum, uint32_t width, uint32_t height, uint32_
         }
     }
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_tonemap_u8");
 }
 
-int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) try {
     if (!path || !rgb8) {
         set_error("rt_write_ppm: null argument");
         return RT_ERR_INVALID;
@@ -279,6 +285,8 @@ int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t
         fprintf(f, "%u %u %u\n", rgb8[3 * p], rgb8[3 * p + 1], rgb8[3 * p + 2]);
     if (f != stdout) fclose(f);
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_write_ppm");
 }
 
 }  // extern "C"

@@ -89,7 +89,7 @@ struct rt_comm {
 
 extern "C" {
 
-int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]) {
+int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]) try {
     if (!id) {
         rth::set_error("rt_comm_unique_id: null argument");
         return RT_ERR_INVALID;
@@ -101,9 +101,11 @@ int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]) {
     RT_NCCL(r, r->GetUniqueId(&u));
     memcpy(id, u.internal, sizeof u.internal);
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_comm_unique_id");
 }
 
-int rt_comm_create(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], int world_size, int rank, rt_comm** out) {
+int rt_comm_create(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], int world_size, int rank, rt_comm** out) try {
     if (!ctx || !id || !out || world_size < 1 || rank < 0 || rank >= world_size) {
         rth::set_error("rt_comm_create: bad argument (world_size %d, rank %d)", world_size, rank);
         return RT_ERR_INVALID;
@@ -123,6 +125,8 @@ int rt_comm_create(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], int world_si
     c->rank = rank;
     *out = c;
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_comm_create");
 }
 
 void rt_comm_destroy(rt_comm* comm) {
@@ -136,7 +140,7 @@ void rt_comm_destroy(rt_comm* comm) {
     delete comm;
 }
 
-int rt_reduce_accum(rt_comm* comm, float* rgb_sum, uint32_t width, uint32_t height, int root) {
+int rt_reduce_accum(rt_comm* comm, float* rgb_sum, uint32_t width, uint32_t height, int root) try {
     if (!comm || !rgb_sum || root >= comm->world) {
         rth::set_error("rt_reduce_accum: bad argument");
         return RT_ERR_INVALID;
@@ -158,6 +162,8 @@ int rt_reduce_accum(rt_comm* comm, float* rgb_sum, uint32_t width, uint32_t heig
     else RT_NCCL(r, r->Reduce(rgb_sum, rgb_sum, count, NCCL_FLOAT32, NCCL_SUM, root, comm->comm, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_reduce_accum");
 }
 
 }  // extern "C"

@@ -236,7 +236,7 @@ int trace_grid(size_t n) {
 // ---------------------------------------------------------------- C ABI
 extern "C" {
 
-int rt_create(int device, rt_ctx** out) {
+int rt_create(int device, rt_ctx** out) try {
     if (!out) {
         rth::set_error("rt_create: null out");
         return RT_ERR_INVALID;
@@ -271,6 +271,8 @@ int rt_create(int device, rt_ctx** out) {
     }
     *out = ctx;
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_create");
 }
 
 void rt_destroy(rt_ctx* ctx) {
@@ -289,7 +291,7 @@ void rt_destroy(rt_ctx* ctx) {
 
 void* rt_stream(rt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) try {
     int rc = check_ctx(ctx, false);
     if (rc != RT_OK) return rc;
     if (!s) {
@@ -485,6 +487,34 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
         }
         if (ok) cull_test |= 1ull << i;
     }
+    // ---- materials, lights, media: records the kernels switch on and loop over.  An unknown kind would fall into
+    // an else branch silently; a checkered medium with a cell size <= 0 or NaN never advances its DDA
+    // (device_shade.h: t_delta = 0), which is a hung GPU rather than an error code.
+    auto finite3 = [](const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); };
+    for (uint32_t i = 0; i < s->n_materials; ++i)
+        if (s->materials[i].kind > RT_MAT_CONDUCTOR) {
+            rth::set_error("rt_upload_scene: material %u: unknown kind %u", i, s->materials[i].kind);
+            return RT_ERR_INVALID;
+        }
+    for (uint32_t i = 0; i < s->n_lights; ++i) {
+        const rt_light& l = s->lights[i];
+        if (l.kind > RT_LIGHT_AREA || !finite3(l.pos) || (l.kind == RT_LIGHT_AREA && !(l.scalar > 0.0f && std::isfinite(l.scalar)))) {
+            rth::set_error("rt_upload_scene: light %u: unknown kind, non-finite position or non-positive radius", i);
+            return RT_ERR_INVALID;
+        }
+    }
+    for (uint32_t i = 0; i < s->n_media; ++i) {
+        const rt_medium& m = s->media[i];
+        bool ok = m.kind <= RT_MEDIUM_CHECKERED && finite3(m.sigma_a) && finite3(m.sigma_s) && std::isfinite(m.g);
+        for (int a = 0; ok && a < 3; ++a) ok = m.sigma_a[a] >= 0.0f && m.sigma_s[a] >= 0.0f;
+        if (ok && m.kind == RT_MEDIUM_CHECKERED)
+            ok = std::isfinite(m.cell_size) && m.cell_size > 0.0f && std::isfinite(m.sigma_a_black) && m.sigma_a_black >= 0.0f &&
+                 std::isfinite(m.sigma_s_black) && m.sigma_s_black >= 0.0f;
+        if (!ok) {
+            rth::set_error("rt_upload_scene: medium %u: unknown kind, negative or non-finite coefficient, or cell_size <= 0", i);
+            return RT_ERR_INVALID;
+        }
+    }
     if (s->initial_medium >= (int32_t)s->n_media || s->initial_medium < RT_MEDIUM_AUTO) {
         rth::set_error("rt_upload_scene: initial_medium out of range");
         return RT_ERR_INVALID;
@@ -579,6 +609,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) {
         }
     }
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_upload_scene");
 }
 
 int rt_initial_medium(const rt_ctx* ctx, int32_t* out) {
@@ -620,7 +652,7 @@ static int launch_trace(rt_ctx* ctx, bool any, const TraceIO& io, size_t n, floa
 
 static bool rays_null(const rt_rays* r) { return !r || !r->ox || !r->oy || !r->oz || !r->dx || !r->dy || !r->dz; }
 
-int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, const rt_hits* hits) {
+int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, const rt_hits* hits) try {
     int rc = check_ctx(ctx, true);
     if (rc != RT_OK) return rc;
     if (rays_null(rays) || !hits || !hits->t) {
@@ -658,10 +690,12 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
     if ((rc = sg.finish()) != RT_OK) return rc;
     RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_trace_closest");
 }
 
 int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, uint8_t* occluded,
-                 uint32_t* n_int, uint32_t* n_tri) {
+                 uint32_t* n_int, uint32_t* n_tri) try {
     int rc = check_ctx(ctx, true);
     if (rc != RT_OK) return rc;
     if (rays_null(rays) || !occluded) {
@@ -701,9 +735,11 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
     if ((rc = sg.finish()) != RT_OK) return rc;
     RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_trace_any");
 }
 
-int rt_trace_closest_noalloc(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, const rt_hits* hits) {
+int rt_trace_closest_noalloc(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, const rt_hits* hits) try {
     int rc = check_ctx(ctx, true);
     if (rc != RT_OK) return rc;
     if (rays_null(rays) || !hits || !hits->t) {
@@ -738,6 +774,8 @@ int rt_trace_closest_noalloc(rt_ctx* ctx, const rt_rays* rays, size_t n, float t
     RT_HIP(hipStreamSynchronize(ctx->stream));
     RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_trace_closest_noalloc");
 }
 
 int rt_set_visit_count_mode(rt_ctx* ctx, uint32_t mode) {

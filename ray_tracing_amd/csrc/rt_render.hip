@@ -739,6 +739,13 @@ struct StageTimer {  // accumulates HIP-event time of one pipeline stage on the 
     hipEvent_t a = nullptr, b = nullptr;
     float ms = 0.0f;
     bool pending = false;
+    StageTimer() = default;
+    StageTimer(const StageTimer&) = delete;
+    StageTimer& operator=(const StageTimer&) = delete;
+    ~StageTimer() {  // rt_render leaves through RT_HIP's early returns: the per-call events go with the scope
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
 };
 
 }  // namespace
@@ -1083,11 +1090,6 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     st.ms_shade = tm[2].ms;
     st.ms_shadow = tm[3].ms;
     st.ms_compact = tm[4].ms;
-    for (int k = 0; k < N_STAGES; ++k)
-        if (timed(k)) {
-            (void)hipEventDestroy(tm[k].a);
-            (void)hipEventDestroy(tm[k].b);
-        }
     if (stats) *stats = st;
     return RT_OK;
 }

@@ -143,6 +143,22 @@ def test_stl_reader_unifies_vertices_on_bit_patterns(tmp_path):
         f.write(b"x" * 80 + struct.pack("<I", 5) + b"\0" * 60)
     with pytest.raises(rt.RtError):
         rt.Mesh.read_stl(p)
+    # a header that announces 2^32 - 1 triangles must be refused from the file's size, before anything is reserved
+    with open(p, "wb") as f:
+        f.write(b"x" * 80 + struct.pack("<I", 0xFFFFFFFF) + b"\0" * 100)
+    with pytest.raises(rt.RtError) as e:
+        rt.Mesh.read_stl(p)
+    assert e.value.code == -4 and "truncated" in str(e.value)
+
+
+def test_distinct_meshes_get_their_own_trees():
+    """configs[4] as the reference builds it (src/main.rs:149-159): one mesh and one BVH per object."""
+    scene = rt.Scene(scenes.multi_mesh_scene(levels=3, copies=4, distinct=True))
+    b = scene.bvhs()
+    assert scene.flat.n_bvhs == 4 and scene.flat.n_tris == 4 * 256
+    nodes = scene.nodes()
+    roots = [nodes["upper"][x.node_offset].tolist() for x in b]
+    assert len({tuple(r) for r in roots}) == 4  # rotated / stretched copies: different bounds, different trees
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_MESHES), reason="reference assets not mounted (GPU box)")

@@ -154,3 +154,16 @@ def test_errors_are_reported_not_thrown(ctx):
     c2.close()
     with pytest.raises(rt.RtError):
         rt.Context(12345)
+    # records the kernels would loop on are validated at upload: a checkered medium whose cell size is 0 never
+    # advances its DDA (testmedium.rs:165-211) -- an error code, not a hung GPU
+    for cell, sig in ((0.0, 0.2), (float("nan"), 0.2), (0.5, -1.0)):
+        d = scenes.volumetric_sphere()
+        d.media[0].cell_size = cell
+        d.media[0].sigma_a[0] = sig
+        with pytest.raises(rt.RtError) as e:
+            ctx.upload(rt.Scene(d))
+        assert e.value.code == -1
+    d = scenes.volumetric_sphere()
+    d.lights[0].kind = 7
+    with pytest.raises(rt.RtError):
+        ctx.upload(rt.Scene(d))
