@@ -85,11 +85,18 @@ struct rt_ctx {
     uint64_t max_paths_in_flight = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     float last_kernel_ms = 0.0f;
+    // rt_render: counts of every bounce arrive in pinned host memory (k_compact_scan_top writes them), one ring slot of
+    // 4 u32 and one event per bounce in flight; event pairs of the stage timers, reused from call to call
+    uint32_t* rb_host = nullptr;
+    hipEvent_t rb_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_pool;
     uint32_t* scratch = nullptr;  // this device's copy of the static scratch array (rt_device.hip), resolved by rt_create
     uint32_t count_mode = RT_COUNT_REFERENCE;  // what rt_trace_*'s n_int / n_tri count (rt_set_visit_count_mode)
 };
 
+constexpr size_t RT_READBACK_RING = 8;  // the host is at most two bounces ahead of the counts it has read
 int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes);
+int rt_ctx_ensure_readback(rt_ctx* ctx);
 
 #ifndef RT_LEAN_OVERFLOW
 #define RT_LEAN_OVERFLOW true  // false: no overflow path in the lean kernels (-1 ms), scenes deeper than the LDS stack take the full ones
@@ -102,3 +109,5 @@ inline bool rt_scene_is_lean(const rt_ctx* ctx) {
 
 // Scheduler parameters of the persistent trace kernels for a launch of n rays on `grid` blocks.
 rtd::TraceTune rt_trace_tune(size_t n, int grid);
+rtd::TuneBase rt_tune_base();
+int rt_trace_grid(size_t n);

@@ -42,6 +42,34 @@ struct TraceTune {
                                      // (lanes waiting for it) x weight
 };
 
+// The launch-independent part of TraceTune (host: rt_tune_base(); RT_TUNE overrides it) and the rule that sizes the
+// rest from the number of rays -- evaluated on the host for rt_trace_*, whose n is an argument, and at the top of
+// rt_render's trace kernels, whose n lives in device memory (rt_render.hip: the host enqueues a bounce before it
+// knows how many paths survived the previous one).
+struct TuneBase {
+    uint32_t chunk;  // 0 = by size: 128 rays per atomic on frame-sized launches, 64 on small ones (finer tail balance)
+    uint32_t refill_min, w_adv, w_node, w_leaf, max_seg;
+};
+__host__ __device__ inline TraceTune make_tune(const TuneBase& b, uint32_t n, uint32_t grid) {
+    TraceTune t;
+    t.chunk = b.chunk ? b.chunk : (n >= (16u << 20) ? 128u : 64u);
+    t.refill_min = b.refill_min;
+    t.w_adv = b.w_adv;
+    t.w_node = b.w_node;
+    t.w_leaf = b.w_leaf;
+    // segments: at most max_seg, each at least 2048 chunks long (a drained segment costs every wave one probe),
+    // never more than the launch has blocks
+    uint32_t seg = n / (t.chunk * 2048u);
+    if (seg > b.max_seg) seg = b.max_seg;
+    if (seg > grid) seg = grid;
+    if (seg < 1u) seg = 1u;
+    t.n_seg = seg;
+    const unsigned long long len = ((unsigned long long)n + seg - 1u) / seg;
+    const unsigned long long rounded = (len + t.chunk - 1u) / t.chunk * t.chunk;
+    t.seg_len = rounded > 0xFFFFFFFFull ? 0xFFFFFFFFu / t.chunk * t.chunk : (uint32_t)rounded;
+    return t;
+}
+
 constexpr uint32_t RAY_NONE = 0xFFFFFFFFu;
 constexpr uint32_t REF_ADVANCE = 0xFFFFFFFFu;  // "current object finished": never a valid leaf ref
 constexpr uint32_t REF_DONE = 0xFFFFFFFEu;     // TRACE_PATH: ray finished, waiting for its continuation

@@ -34,44 +34,37 @@ int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes) {
     return ctx->overflow.ensure(lanes * ctx->overflow_levels * sizeof(uint32_t));
 }
 
-TraceTune rt_trace_tune(size_t n, int grid) {
+// Workgroups of a trace launch over n rays: one lane per ray up to the full persistent grid.
+int rt_trace_grid(size_t n) {
+    size_t blocks = (n + RT_BLOCK - 1) / RT_BLOCK;
+    if (blocks > (size_t)RT_TRACE_GRID) blocks = RT_TRACE_GRID;
+    return blocks == 0 ? 1 : (int)blocks;
+}
+
+int rt_ctx_ensure_readback(rt_ctx* ctx) {
+    if (ctx->rb_host) return RT_OK;
+    RT_HIP(hipHostMalloc((void**)&ctx->rb_host, RT_READBACK_RING * 4 * sizeof(uint32_t), hipHostMallocDefault));
+    memset(ctx->rb_host, 0, RT_READBACK_RING * 4 * sizeof(uint32_t));
+    for (size_t i = 0; i < RT_READBACK_RING; ++i) RT_HIP(hipEventCreateWithFlags(&ctx->rb_ev[i], hipEventDisableTiming));
+    return RT_OK;
+}
+
+TuneBase rt_tune_base() {
     // Defaults from sweeps on MI355X (profiles/r01/tuning.md);
     // RT_TUNE="chunk,refill,w_adv,w_node,w_leaf,max_seg" overrides them for experiments.
-    static unsigned v[6] = {0, 0, 0, 0, 0, 0};
-    static bool have_env = false;
-    if (v[1] == 0) {
+    static TuneBase base = [] {
         unsigned d[6] = {0, 24, 1, 3, 4, WORK_MAX_SEG};
-        const char* e = getenv("RT_TUNE");
-        if (e) {
-            sscanf(e, "%u,%u,%u,%u,%u,%u", &d[0], &d[1], &d[2], &d[3], &d[4], &d[5]);
-            have_env = true;
-        }
+        if (const char* e = getenv("RT_TUNE")) sscanf(e, "%u,%u,%u,%u,%u,%u", &d[0], &d[1], &d[2], &d[3], &d[4], &d[5]);
         if (d[0] > 4096) d[0] = 0;
         if (d[1] == 0 || d[1] > 64) d[1] = 24;
         if (!d[2] || !d[3] || !d[4]) d[2] = 1, d[3] = 3, d[4] = 4;
         if (d[5] == 0 || d[5] > WORK_MAX_SEG) d[5] = WORK_MAX_SEG;
-        for (int i = 0; i < 6; ++i) v[i] = d[i];
-    }
-    (void)have_env;
-    TraceTune t;
-    // chunk: 128 rays per atomic on frame-sized launches, 64 on small ones (finer tail balance)
-    t.chunk = v[0] ? v[0] : (n >= ((size_t)16 << 20) ? 128u : 64u);
-    t.refill_min = v[1];
-    t.w_adv = v[2];
-    t.w_node = v[3];
-    t.w_leaf = v[4];
-    // segments: at most max_seg, each at least 2048 chunks long (a drained segment costs every wave
-    // one probe), never more than the launch has blocks
-    uint64_t seg = n / ((uint64_t)t.chunk * 2048);
-    if (seg > v[5]) seg = v[5];
-    if (seg > (uint64_t)grid) seg = (uint64_t)grid;
-    if (seg < 1) seg = 1;
-    t.n_seg = (uint32_t)seg;
-    uint64_t len = (n + seg - 1) / seg;
-    len = (len + t.chunk - 1) / t.chunk * t.chunk;
-    t.seg_len = (uint32_t)len;
-    return t;
+        return TuneBase{d[0], d[1], d[2], d[3], d[4], d[5]};
+    }();
+    return base;
 }
+
+TraceTune rt_trace_tune(size_t n, int grid) { return make_tune(rt_tune_base(), (uint32_t)n, (uint32_t)grid); }
 
 // ---------------------------------------------------------------- kernels
 struct TraceIO {  // caller-provided SoA ray batch and hit arrays (rt_rays / rt_hits)
@@ -224,12 +217,7 @@ int check_ctx(rt_ctx* ctx, bool need_scene) {
     return RT_OK;
 }
 
-int trace_grid(size_t n) {
-    size_t blocks = (n + RT_BLOCK - 1) / RT_BLOCK;
-    if (blocks > (size_t)RT_TRACE_GRID) blocks = RT_TRACE_GRID;
-    if (blocks == 0) blocks = 1;
-    return (int)blocks;
-}
+int trace_grid(size_t n) { return rt_trace_grid(n); }
 
 }  // namespace
 
@@ -283,6 +271,11 @@ void rt_destroy(rt_ctx* ctx) {
                       &ctx->overflow, &ctx->path_state, &ctx->queues, &ctx->counters, &ctx->sample_sum};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->staging) b.release();
+    if (ctx->rb_host) (void)hipHostFree(ctx->rb_host);
+    for (hipEvent_t e : ctx->rb_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_pool)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ev[0]) (void)hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) (void)hipEventDestroy(ctx->ev[1]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

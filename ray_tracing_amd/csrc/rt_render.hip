@@ -49,8 +49,13 @@ struct PathArrays {      // SoA over slots
     uint32_t* block_off; // [2][blocks]: exclusive scan inside the block's scan group
     uint32_t* group_tot; // [2][groups]: totals of each group of SCAN_GROUP blocks
     uint32_t* group_off; // [2][groups]: exclusive scan of the group totals
-    uint32_t* totals;    // [0] next live count, [1] shadow count
-    uint32_t* work;      // extend work counters [0, WORK_U32), shadow work counters [WORK_U32, 2*WORK_U32) (zeroed per iteration)
+    uint32_t* counts;    // [2][4], ping-pong over the bounces: [0] live paths of the bounce, [1] shadow rays of the bounce
+                         // before it.  Every kernel reads its n from here: the host enqueues a bounce before it knows how
+                         // many paths survived the previous one (rt_render below).
+    uint32_t* counts_host;  // the same two numbers per bounce, written by k_compact_scan_top into pinned host memory
+    uint32_t max_blocks, max_groups;  // strides of block_cnt / block_off and group_tot / group_off
+    uint32_t* work;      // extend work counters [0, WORK_U32), shadow work counters [WORK_U32, 2*WORK_U32); zeroed by
+                         // k_compact_scan_top of every bounce
     unsigned long long* tail;   // k_tail totals (see k_tail)
     unsigned long long* visit; // [0] n_int extend, [1] n_tri extend, [2] n_int shadow, [3] n_tri shadow
 };
@@ -73,6 +78,10 @@ RT_DEV float pack_medium(int medium, bool prev_specular) {
 __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, RenderParams rp, uint32_t n_paths) {
     uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (slot >= n_paths) return;
+    if (slot == 0) {  // bounce 0: every path is alive, no shadow rays pending
+        pa.counts[0] = n_paths;
+        pa.counts[1] = 0u;
+    }
     uint32_t pixel = slot % rp.npix, s_local = slot / rp.npix;
     uint32_t i = pixel % rp.width, j = pixel / rp.width;
     Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + s_local, 0u, 0u};
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
     }
     pa.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
     pa.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    pa.queue[0][slot] = slot;
+    if (!rp.implicit_first) pa.queue[0][slot] = slot;  // implicit: nobody looks the identity up
 }
 
 // ---------------------------------------------------------------- extend
@@ -146,11 +155,13 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
 };
 
 template <int COUNT>
-__global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n, uint32_t first,
-                                                     uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
+__global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, const uint32_t* counts, uint32_t first,
+                                                     uint32_t* work_counter, TuneBase base, uint32_t* overflow,
                                                      uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t n = counts[0];
+    const TraceTune tune = make_tune(base, n, gridDim.x);
     ExtendIO io{pa, queue, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
     trace_loop<TRACE_CLOSEST, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                              lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
@@ -158,11 +169,13 @@ __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t*
 }
 
 // The same kernel for scenes whose objects are meshes and planes (rtd::SceneFeatures): fewer registers, more waves.
-__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n, uint32_t first,
-                                                 uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
+__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const uint32_t* queue, const uint32_t* counts, uint32_t first,
+                                                 uint32_t* work_counter, TuneBase base, uint32_t* overflow,
                                                  uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t n = counts[0];
+    const TraceTune tune = make_tune(base, n, gridDim.x);
     ExtendIO io{pa, queue, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
     trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                                   lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
@@ -206,20 +219,24 @@ struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds it
 
 // path_integrator.rs:219: the shadow ray is tested over T_MIN..T_MAX, not up to the light.
 template <int COUNT>
-__global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, uint32_t n, uint32_t* work_counter,
-                                                     TraceTune tune, uint32_t* overflow, uint32_t overflow_stride) {
+__global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, const uint32_t* counts, uint32_t* work_counter,
+                                                     TuneBase base, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_ANY * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t n = counts[1];
+    const TraceTune tune = make_tune(base, n, gridDim.x);
     ShadowIO io{pa, 0ull, 0ull};
     trace_loop<TRACE_ANY, COUNT, RT_STACK_ANY, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     if (COUNT) add_visits(&pa.visit[2], io.n_int, io.n_tri);
 }
 
-__global__ RT_TRACE_ATTR_LEAN_ANY void k_shadow_lean(DScene sc, PathArrays pa, uint32_t n, uint32_t* work_counter,
-                                                     TraceTune tune, uint32_t* overflow, uint32_t overflow_stride) {
+__global__ RT_TRACE_ATTR_LEAN_ANY void k_shadow_lean(DScene sc, PathArrays pa, const uint32_t* counts, uint32_t* work_counter,
+                                                     TuneBase base, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN_ANY * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t n = counts[1];
+    const TraceTune tune = make_tune(base, n, gridDim.x);
     ShadowIO io{pa, 0ull, 0ull};
     trace_loop<TRACE_ANY, false, RT_STACK_LEAN_ANY, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                               lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
@@ -397,8 +414,10 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
 }
 
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa, RenderParams rp,
-                                                       const uint32_t* queue, uint32_t n, uint32_t n_blocks) {
+                                                       const uint32_t* queue, const uint32_t* counts) {
     __shared__ uint32_t wave_cnt[2][SHADE_BLOCK / 64];
+    const uint32_t n = counts[0];
+    if (blockIdx.x * SHADE_BLOCK >= n) return;  // the grid is sized from an upper bound of n (uniform per block)
     uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
     uint32_t flags = 0;
     if (i < n) {
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     if (threadIdx.x < 2) {
         uint32_t s = 0;
         for (int w = 0; w < SHADE_BLOCK / 64; ++w) s += wave_cnt[threadIdx.x][w];
-        pa.block_cnt[threadIdx.x * n_blocks + blockIdx.x] = s;
+        pa.block_cnt[threadIdx.x * pa.max_blocks + blockIdx.x] = s;
     }
 }
 
@@ -513,10 +532,12 @@ RT_DEV unsigned long long wave_sum_u64(unsigned long long v) {
 // pa.tail[0..7]: closest rays, shadow rays, n_int, n_tri (closest), n_int, n_tri (shadow), max iterations, unused
 template <int COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, RenderParams rp, const uint32_t* queue,
-                                                   uint32_t n, uint32_t* work_counter, TraceTune tune,
+                                                   const uint32_t* counts, uint32_t* work_counter, TuneBase base,
                                                    uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t n = counts[0];
+    const TraceTune tune = make_tune(base, n, gridDim.x);
     TailIO io{pa, queue, &sc, &rp, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false};
     trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                           lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
@@ -583,11 +604,13 @@ struct MixedIO {
 };
 
 template <int COUNT>
-__global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n_shadow, uint32_t n,
-                                      uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
+__global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, const uint32_t* queue, const uint32_t* counts,
+                                      uint32_t* work_counter, TuneBase base, uint32_t* overflow,
                                       uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t n_shadow = counts[1], n = n_shadow + counts[0];  // shadow rays of this bounce, then the rays of the next
+    const TraceTune tune = make_tune(base, n, gridDim.x);
     MixedIO io{pa, queue, n_shadow, 0ull, 0ull, 0ull, 0ull};
     trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                           lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
@@ -597,11 +620,13 @@ __global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, const uint32_t* 
     }
 }
 
-__global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays pa, const uint32_t* queue, uint32_t n_shadow,
-                                                uint32_t n, uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
+__global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays pa, const uint32_t* queue, const uint32_t* counts,
+                                                uint32_t* work_counter, TuneBase base, uint32_t* overflow,
                                                 uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t n_shadow = counts[1], n = n_shadow + counts[0];
+    const TraceTune tune = make_tune(base, n, gridDim.x);
     MixedIO io{pa, queue, n_shadow, 0ull, 0ull, 0ull, 0ull};
     trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN,
                                                                          __builtin_inff(), lds_stack + threadIdx.x,
@@ -640,44 +665,60 @@ RT_DEV uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wave_sum /*[16]*/, ui
     return x - v + wave_sum[wave];
 }
 
-__global__ __launch_bounds__(1024) void k_compact_scan_groups(PathArrays pa, uint32_t n_blocks, uint32_t n_groups) {
+__global__ __launch_bounds__(1024) void k_compact_scan_groups(PathArrays pa, const uint32_t* counts) {
     __shared__ uint32_t wave_sum[2][16];
     __shared__ uint32_t total[2];
+    const uint32_t n = counts[0];
+    const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
+    if (blockIdx.x * SCAN_GROUP >= n_blocks) return;  // grid sized from an upper bound of n
     const uint32_t b = blockIdx.x * SCAN_GROUP + threadIdx.x;
     for (int q = 0; q < 2; ++q) {
-        const uint32_t v = b < n_blocks ? pa.block_cnt[q * n_blocks + b] : 0u;
+        const uint32_t v = b < n_blocks ? pa.block_cnt[q * pa.max_blocks + b] : 0u;
         const uint32_t e = block_excl_scan_1024(v, wave_sum[q], &total[q]);
-        if (b < n_blocks) pa.block_off[q * n_blocks + b] = e;
+        if (b < n_blocks) pa.block_off[q * pa.max_blocks + b] = e;
     }
-    if (threadIdx.x < 2) pa.group_tot[threadIdx.x * n_groups + blockIdx.x] = total[threadIdx.x];
+    if (threadIdx.x < 2) pa.group_tot[threadIdx.x * pa.max_groups + blockIdx.x] = total[threadIdx.x];
 }
 
-__global__ __launch_bounds__(1024) void k_compact_scan_top(PathArrays pa, uint32_t n_groups) {
+// One workgroup: scans the group totals, publishes the counts of the next bounce -- to device memory for the kernels
+// that follow in the stream, and to pinned host memory for the host, which reads them a bounce later -- and zeroes
+// the work counters of the trace launches that follow.
+__global__ __launch_bounds__(1024) void k_compact_scan_top(PathArrays pa, const uint32_t* counts, uint32_t* counts_out,
+                                                           uint32_t* counts_host) {
     __shared__ uint32_t wave_sum[2][16];
     __shared__ uint32_t total[2];
+    const uint32_t n = counts[0];
+    const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
+    const uint32_t n_groups = (n_blocks + SCAN_GROUP - 1) / SCAN_GROUP;
     const uint32_t per = (n_groups + 1023u) / 1024u;  // <= 8
     const uint32_t begin = threadIdx.x * per, end = min(begin + per, n_groups);
     for (int q = 0; q < 2; ++q) {
         uint32_t s = 0;
-        for (uint32_t g = begin; g < end; ++g) s += pa.group_tot[q * n_groups + g];
+        for (uint32_t g = begin; g < end; ++g) s += pa.group_tot[q * pa.max_groups + g];
         uint32_t run = block_excl_scan_1024(s, wave_sum[q], &total[q]);
         for (uint32_t g = begin; g < end; ++g) {
-            const uint32_t c = pa.group_tot[q * n_groups + g];
-            pa.group_off[q * n_groups + g] = run;
+            const uint32_t c = pa.group_tot[q * pa.max_groups + g];
+            pa.group_off[q * pa.max_groups + g] = run;
             run += c;
         }
     }
-    if (threadIdx.x < 2) pa.totals[threadIdx.x] = total[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < 2u * WORK_U32; i += 1024u) pa.work[i] = 0u;
+    if (threadIdx.x < 2) {
+        counts_out[threadIdx.x] = total[threadIdx.x];  // [0] paths alive after this bounce, [1] its shadow rays
+        counts_host[threadIdx.x] = total[threadIdx.x];
+        __threadfence_system();
+    }
 }
 
 // Stable scatter: position = block offset + waves before + rank inside the wave ballot.
 __global__ __launch_bounds__(SHADE_BLOCK) void k_compact_scatter(PathArrays pa, const uint32_t* queue,
-                                                                 uint32_t* next_queue, uint32_t n, uint32_t n_blocks,
-                                                                 uint32_t n_groups) {
+                                                                 uint32_t* next_queue, const uint32_t* counts, uint32_t identity) {
     __shared__ uint32_t wave_cnt[2][SHADE_BLOCK / 64];
+    const uint32_t n = counts[0];
+    if (blockIdx.x * SHADE_BLOCK >= n) return;
     uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
     uint32_t flags = i < n ? pa.qflags[i] : 0u;
-    uint32_t slot = i < n ? queue[i] : 0u;
+    uint32_t slot = i < n ? (identity ? i : queue[i]) : 0u;  // the first bounce's queue is the identity: no look-up
     unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
     unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
     uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -693,7 +734,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_compact_scatter(PathArrays pa, 
         next_queue[pos + (uint32_t)__popcll(alive & below)] = slot;
     }
     if (flags & QF_SHADOW) {
-        uint32_t pos = pa.group_off[n_groups + blockIdx.x / SCAN_GROUP] + pa.block_off[n_blocks + blockIdx.x];
+        uint32_t pos = pa.group_off[pa.max_groups + blockIdx.x / SCAN_GROUP] + pa.block_off[pa.max_blocks + blockIdx.x];
         for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[1][w];
         pa.shadow_q[pos + (uint32_t)__popcll(shadow & below)] = slot;
     }
@@ -735,23 +776,10 @@ bool is_device_ptr(const void* p) {
     return a.type == hipMemoryTypeDevice;
 }
 
-struct StageTimer {  // accumulates HIP-event time of one pipeline stage on the context stream
-    hipEvent_t a = nullptr, b = nullptr;
-    float ms = 0.0f;
-    bool pending = false;
-    StageTimer() = default;
-    StageTimer(const StageTimer&) = delete;
-    StageTimer& operator=(const StageTimer&) = delete;
-    ~StageTimer() {  // rt_render leaves through RT_HIP's early returns: the per-call events go with the scope
-        if (a) (void)hipEventDestroy(a);
-        if (b) (void)hipEventDestroy(b);
-    }
-};
-
 }  // namespace
 
 extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp_first, uint32_t spp_count,
-                         uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats) {
+                         uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats) try {
     if (!ctx || !rgb_sum) {
         rth::set_error("rt_render: null argument");
         return RT_ERR_INVALID;
@@ -803,13 +831,15 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
+    const uint32_t max_groups = max_blocks / SCAN_GROUP + 1;
     size_t o_ray_o = carve(P * 16), o_ray_d = carve(P * 16), o_beta = carve(P * 16), o_rad = carve(P * 16),
            o_hit_a = carve(P * 16), o_hit_b = carve(P * 8), o_sh_d = carve(P * 16), o_sh_c = carve(P * 16), o_q0 = carve(P * 4), o_q1 = carve(P * 4),
            o_sq = carve(P * 4), o_qf = carve(P * 4), o_bc = carve((size_t)max_blocks * 8),
-           o_bo = carve((size_t)max_blocks * 8), o_gt = carve(((size_t)max_blocks / 1024 + 1) * 8),
-           o_go = carve(((size_t)max_blocks / 1024 + 1) * 8), o_tot = carve(256), o_vis = carve(256), o_tail = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
+           o_bo = carve((size_t)max_blocks * 8), o_gt = carve((size_t)max_groups * 8),
+           o_go = carve((size_t)max_groups * 8), o_cnt = carve(256), o_vis = carve(256), o_tail = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
     int rc = ctx->path_state.ensure(off);
     if (rc != RT_OK) return rc;
+    if ((rc = rt_ctx_ensure_readback(ctx)) != RT_OK) return rc;
     char* base = (char*)ctx->path_state.p;
     PathArrays pa;
     pa.ray_o = (float4*)(base + o_ray_o);
@@ -828,7 +858,10 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     pa.block_off = (uint32_t*)(base + o_bo);
     pa.group_tot = (uint32_t*)(base + o_gt);
     pa.group_off = (uint32_t*)(base + o_go);
-    pa.totals = (uint32_t*)(base + o_tot);
+    pa.counts = (uint32_t*)(base + o_cnt);
+    pa.counts_host = ctx->rb_host;
+    pa.max_blocks = max_blocks;
+    pa.max_groups = max_groups;
     pa.work = (uint32_t*)(base + o_work);
     pa.visit = (unsigned long long*)(base + o_vis);
     pa.tail = (unsigned long long*)(base + o_tail);
@@ -864,37 +897,52 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         const char* e = getenv("RT_TAIL_PATHS");
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 32768u;
     }();
+    static const uint32_t async_below = [] {  // RT_ASYNC_BELOW: bounces with at most this many paths are enqueued
+        const char* e = getenv("RT_ASYNC_BELOW");  // without waiting for their exact counts (0: always wait)
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : (16u << 20);
+    }();
     const bool timing = (flags & RT_RENDER_TIME_STAGES) != 0;
-    // HIP events on the library's stream around every launch of a stage.  k_extend (index 1, the kernel
-    // the roofline figure is about) is always timed -- two event records per iteration; the other
-    // stages only with RT_RENDER_TIME_STAGES.
-    constexpr int N_STAGES = 6;
-    StageTimer tm[N_STAGES];  // generate, extend, shade, shadow, compact, tail
+    // HIP events on the library's stream around every launch of a stage, summed per stage after the frame's last
+    // synchronisation (the host runs ahead of the device, so a span cannot be read back where it is recorded).
+    // k_extend (stage 1, the kernel the roofline figure is about) and the mixed / tail launches (stage 5) are always
+    // timed; the other stages only with RT_RENDER_TIME_STAGES.  The event pairs are cached in the context.
+    constexpr int N_STAGES = 6;  // generate, extend, shade, shadow, compact, tail
+    float stage_ms[N_STAGES] = {0, 0, 0, 0, 0, 0};
+    struct Span {
+        int stage;
+        size_t pair;
+    };
+    std::vector<Span> spans;
+    size_t pairs_used = 0;
     auto timed = [&](int k) { return timing || k == 1 || k == 5; };
-    for (int k = 0; k < N_STAGES; ++k)
-        if (timed(k)) {
-            RT_HIP(hipEventCreate(&tm[k].a));
-            RT_HIP(hipEventCreate(&tm[k].b));
-        }
     auto t_begin = [&](int k) -> int {
-        if (timed(k)) RT_HIP(hipEventRecord(tm[k].a, stream));
+        if (!timed(k)) return RT_OK;
+        if (pairs_used == ctx->ev_pool.size() / 2) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            RT_HIP(hipEventCreate(&e0));
+            ctx->ev_pool.push_back(e0);
+            hipError_t e = hipEventCreate(&e1);
+            ctx->ev_pool.push_back(e1);  // a null second event is destroyed safely by rt_destroy
+            RT_HIP(e);
+        }
+        spans.push_back({k, pairs_used});
+        RT_HIP(hipEventRecord(ctx->ev_pool[2 * pairs_used], stream));
         return RT_OK;
     };
     auto t_end = [&](int k) -> int {
-        if (timed(k)) {
-            RT_HIP(hipEventRecord(tm[k].b, stream));
-            tm[k].pending = true;
-        }
+        if (!timed(k)) return RT_OK;
+        RT_HIP(hipEventRecord(ctx->ev_pool[2 * pairs_used + 1], stream));
+        ++pairs_used;
         return RT_OK;
     };
-    auto t_collect = [&]() -> int {  // after a stream sync
-        for (StageTimer& t : tm)
-            if (t.pending) {
-                float ms = 0.0f;
-                RT_HIP(hipEventElapsedTime(&ms, t.a, t.b));
-                t.ms += ms;
-                t.pending = false;
-            }
+    auto t_collect = [&]() -> int {  // after the stream has been synchronised
+        for (const Span& sp : spans) {
+            float ms = 0.0f;
+            RT_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[2 * sp.pair], ctx->ev_pool[2 * sp.pair + 1]));
+            stage_ms[sp.stage] += ms;
+        }
+        spans.clear();
+        pairs_used = 0;
         return RT_OK;
     };
 
@@ -909,6 +957,66 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     rp.depth = depth;
     rp.k0 = (uint32_t)seed;
     rp.k1 = (uint32_t)(seed >> 32);
+    const TuneBase tune = rt_tune_base();
+    uint32_t* const work_ext = pa.work;                   // closest-hit launches and the tail kernel
+    uint32_t* const work_sh = pa.work + rtd::WORK_U32;    // shadow and mixed launches
+
+    // kernel selection by counting mode / scene features, one place each
+    auto launch_extend = [&](int grid, const uint32_t* queue, const uint32_t* cnt, uint32_t first) {
+        if (count == rtd::COUNT_REFERENCE)
+            hipLaunchKernelGGL(k_extend<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
+        else if (count == rtd::COUNT_FETCHES)
+            hipLaunchKernelGGL(k_extend<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
+        else if (lean)
+            hipLaunchKernelGGL(k_extend_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
+        else
+            hipLaunchKernelGGL(k_extend<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
+    };
+    auto launch_shadow = [&](int grid, const uint32_t* cnt) {
+        if (count == rtd::COUNT_REFERENCE)
+            hipLaunchKernelGGL(k_shadow<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
+        else if (count == rtd::COUNT_FETCHES)
+            hipLaunchKernelGGL(k_shadow<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
+        else if (lean)
+            hipLaunchKernelGGL(k_shadow_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
+        else
+            hipLaunchKernelGGL(k_shadow<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
+    };
+    auto launch_mixed = [&](int grid, const uint32_t* queue_next, const uint32_t* cnt) {
+        if (count == rtd::COUNT_REFERENCE)
+            hipLaunchKernelGGL(k_mixed<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue_next, cnt, work_sh, tune, overflow, ostride);
+        else if (count == rtd::COUNT_FETCHES)
+            hipLaunchKernelGGL(k_mixed<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue_next, cnt, work_sh, tune, overflow, ostride);
+        else if (lean)
+            hipLaunchKernelGGL(k_mixed_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue_next, cnt, work_sh, tune, overflow, ostride);
+        else
+            hipLaunchKernelGGL(k_mixed<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue_next, cnt, work_sh, tune, overflow, ostride);
+    };
+    auto launch_tail = [&](int grid, const uint32_t* queue, const uint32_t* cnt) {
+        if (count == rtd::COUNT_REFERENCE)
+            hipLaunchKernelGGL(k_tail<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp, queue, cnt, work_ext, tune, overflow, ostride);
+        else if (count == rtd::COUNT_FETCHES)
+            hipLaunchKernelGGL(k_tail<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp, queue, cnt, work_ext, tune, overflow, ostride);
+        else
+            hipLaunchKernelGGL(k_tail<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp, queue, cnt, work_ext, tune, overflow, ostride);
+    };
+
+    // What the host remembers of a bounce: which launches it enqueued, and the counts k_compact_scan_top published
+    // for it (read from pinned memory once the event recorded behind that kernel has completed).
+    struct Bounce {
+        bool extend = false, mixed = false, shadow = false, got = false;
+        uint32_t n_next = 0, n_shadow = 0;  // paths alive after the bounce, shadow rays of the bounce
+    };
+    std::vector<Bounce> hist;
+    auto wait_counts = [&](size_t k) -> int {
+        if (hist[k].got) return RT_OK;
+        RT_HIP(hipEventSynchronize(ctx->rb_ev[k % RT_READBACK_RING]));
+        const volatile uint32_t* h = ctx->rb_host + 4 * (k % RT_READBACK_RING);
+        hist[k].n_next = h[0];
+        hist[k].n_shadow = h[1];
+        hist[k].got = true;
+        return RT_OK;
+    };
 
     if (spp_count == 0) RT_HIP(hipMemsetAsync(d_sum, 0, sum_bytes, stream));
     bool first_batch = true;
@@ -920,143 +1028,137 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         // every path's state from memory)
         const bool implicit = depth > 0 && !(use_tail && n_paths <= tail_paths) && getenv("RT_NO_IMPLICIT") == nullptr;
         rp.implicit_first = implicit ? 1u : 0u;
+        RT_HIP(hipMemsetAsync(pa.work, 0, 2 * rtd::WORK_U32 * 4, stream));
         if ((rc = t_begin(0)) != RT_OK) return rc;
         hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, pa, rp, n_paths);
         if ((rc = t_end(0)) != RT_OK) return rc;
         st.paths += n_paths;
         st.batches += 1;
 
-        uint32_t n = depth > 0 ? n_paths : 0;
+        // ---- the wavefront loop.  n_ub is an UPPER BOUND of the paths alive at bounce k: exact while bounces are big
+        // (the host waits for the counts of bounce k before it enqueues bounce k + 1: a round trip of tens of
+        // microseconds against launches of milliseconds, and exact counts pick the launch shapes), one bounce old once
+        // they are small (n_ub <= async_below): then the host enqueues bounce k + 1 while the device still works on
+        // bounce k, with grids sized from the count of bounce k -- paths only die, so it is a bound -- and every
+        // kernel takes its true n from device memory.  That removes the host round trip and the idle gap behind it
+        // from every late bounce (0.1 ms each, profiles/r02/tuning.md).
+        hist.clear();
+        uint32_t n_ub = depth > 0 ? n_paths : 0;
         int cur = 0;
-        uint32_t iter = 0;
+        size_t k = 0;
+        uint32_t tail_iters_total = 0;
         bool extend_done = false;  // the rays of this bounce were traced by the previous bounce's mixed launch
-        while (n > 0) {
-            if (iter >= 1u << 20) {
+        while (n_ub > 0) {
+            if (k >= (size_t)1 << 20) {
                 rth::set_error("rt_render: wavefront did not drain after 2^20 iterations");
                 return RT_ERR_LIMIT;
             }
-            const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
-            const int tgrid = (int)std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
-            RT_HIP(hipMemsetAsync(pa.work, 0, 2 * rtd::WORK_U32 * 4, stream));
-            rp.bounce = iter + 1;  // iteration k of `while depth > 0` draws from RNG bounce k+1 (bounce 0: camera jitter)
-            const uint32_t first_implicit = (implicit && iter == 0) ? 1u : 0u;
+            const uint32_t* cnt_in = pa.counts + 4 * (k & 1);
+            uint32_t* cnt_out = pa.counts + 4 * ((k + 1) & 1);
+            rp.bounce = (uint32_t)k + 1;  // iteration k of `while depth > 0` draws from RNG bounce k+1 (bounce 0: camera jitter)
+            const uint32_t first_implicit = (implicit && k == 0) ? 1u : 0u;
             rp.implicit_first = first_implicit;
-            if (use_tail && n <= tail_paths) {  // few paths left: one launch takes them to their end
+            if (use_tail && n_ub <= tail_paths) {  // few paths left: one launch takes them to their end
                 RT_HIP(hipMemsetAsync(pa.tail + 6, 0, 8, stream));
                 if ((rc = t_begin(5)) != RT_OK) return rc;
-                if (count == rtd::COUNT_REFERENCE)
-                    hipLaunchKernelGGL(k_tail<rtd::COUNT_REFERENCE>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
-                                       pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
-                else if (count == rtd::COUNT_FETCHES)
-                    hipLaunchKernelGGL(k_tail<rtd::COUNT_FETCHES>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
-                                       pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
-                else
-                    hipLaunchKernelGGL(k_tail<rtd::COUNT_NONE>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp,
-                                       pa.queue[cur], n, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
+                launch_tail(rt_trace_grid(n_ub), pa.queue[cur], cnt_in);
                 if ((rc = t_end(5)) != RT_OK) return rc;
                 unsigned long long tail_iters = 0;
                 RT_HIP(hipMemcpyAsync(&tail_iters, pa.tail + 6, 8, hipMemcpyDeviceToHost, stream));
                 RT_HIP(hipStreamSynchronize(stream));
-                if ((rc = t_collect()) != RT_OK) return rc;
-                st.paths_tail += n;
-                st.launches_tail += 1;
-                iter += (uint32_t)tail_iters;
+                if (k > 0 && (rc = wait_counts(k - 1)) != RT_OK) return rc;
+                const uint32_t n_exact = k > 0 ? hist[k - 1].n_next : n_paths;
+                if (n_exact > 0) {
+                    st.paths_tail += n_exact;
+                    st.launches_tail += 1;
+                }
+                tail_iters_total = (uint32_t)tail_iters;
                 break;
             }
+            hist.emplace_back();
+            Bounce& bn = hist.back();
             if (!extend_done) {
-            if ((rc = t_begin(1)) != RT_OK) return rc;
-            if (count == rtd::COUNT_REFERENCE)
-                hipLaunchKernelGGL(k_extend<rtd::COUNT_REFERENCE>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                   pa.queue[cur], n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
-            else if (count == rtd::COUNT_FETCHES)
-                hipLaunchKernelGGL(k_extend<rtd::COUNT_FETCHES>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                   pa.queue[cur], n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
-            else if (lean)
-                hipLaunchKernelGGL(k_extend_lean, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, pa.queue[cur],
-                                   n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
-            else
-                hipLaunchKernelGGL(k_extend<rtd::COUNT_NONE>, dim3(tgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                   pa.queue[cur], n, first_implicit, pa.work, rt_trace_tune(n, tgrid), overflow, ostride);
-            if ((rc = t_end(1)) != RT_OK) return rc;
-            st.rays_closest += n;
-            st.launches_extend += 1;
+                if ((rc = t_begin(1)) != RT_OK) return rc;
+                launch_extend(rt_trace_grid(n_ub), pa.queue[cur], cnt_in, first_implicit);
+                if ((rc = t_end(1)) != RT_OK) return rc;
+                bn.extend = true;
             }
             extend_done = false;
 
+            const uint32_t n_blocks = (n_ub + SHADE_BLOCK - 1) / SHADE_BLOCK;
             if ((rc = t_begin(2)) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pa, rp,
-                               pa.queue[cur], n, n_blocks);
+            hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pa, rp, pa.queue[cur], cnt_in);
             if ((rc = t_end(2)) != RT_OK) return rc;
 
             if ((rc = t_begin(4)) != RT_OK) return rc;
             const uint32_t n_groups = (n_blocks + SCAN_GROUP - 1) / SCAN_GROUP;
-            hipLaunchKernelGGL(k_compact_scan_groups, dim3(n_groups), dim3(1024), 0, stream, pa, n_blocks, n_groups);
-            hipLaunchKernelGGL(k_compact_scan_top, dim3(1), dim3(1024), 0, stream, pa, n_groups);
+            hipLaunchKernelGGL(k_compact_scan_groups, dim3(n_groups), dim3(1024), 0, stream, pa, cnt_in);
+            hipLaunchKernelGGL(k_compact_scan_top, dim3(1), dim3(1024), 0, stream, pa, cnt_in, cnt_out,
+                               ctx->rb_host + 4 * (k % RT_READBACK_RING));
             hipLaunchKernelGGL(k_compact_scatter, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, pa, pa.queue[cur],
-                               pa.queue[cur ^ 1], n, n_blocks, n_groups);
+                               pa.queue[cur ^ 1], cnt_in, first_implicit);
             if ((rc = t_end(4)) != RT_OK) return rc;
+            RT_HIP(hipEventRecord(ctx->rb_ev[k % RT_READBACK_RING], stream));
 
-            uint32_t totals[2];
-            RT_HIP(hipMemcpyAsync(totals, pa.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
-            RT_HIP(hipStreamSynchronize(stream));
-            if ((rc = t_collect()) != RT_OK) return rc;
-            const uint32_t n_next = totals[0], n_shadow = totals[1];
-            if (n_next > n || n_shadow > n) {
+            // bounds of the next bounce's rays and of this bounce's shadow rays
+            uint32_t nn_ub, ns_ub;
+            if (n_ub > async_below) {  // big bounce: wait for its exact counts
+                if ((rc = wait_counts(k)) != RT_OK) return rc;
+                nn_ub = bn.n_next;
+                ns_ub = bn.n_shadow;
+                if (nn_ub > n_ub || ns_ub > n_ub) {
+                    rth::set_error("rt_render: compaction produced impossible counts");
+                    return RT_ERR_HIP;
+                }
+            } else {  // small bounce: the counts of the bounce BEFORE it have arrived meanwhile (or will, without idling the device)
+                if (k > 0 && (rc = wait_counts(k - 1)) != RT_OK) return rc;
+                nn_ub = ns_ub = k > 0 ? std::min(n_ub, hist[k - 1].n_next) : n_ub;
+            }
+            const bool tail_next = use_tail && nn_ub <= tail_paths;  // the tail kernel traces its own first ray
+            if (use_mix && ns_ub > 0 && nn_ub > 0 && !tail_next && (uint64_t)ns_ub + nn_ub <= mix_paths) {
+                // the shadow rays of this bounce and the rays of the next one in one launch
+                if ((rc = t_begin(5)) != RT_OK) return rc;
+                launch_mixed(rt_trace_grid((size_t)ns_ub + nn_ub), pa.queue[cur ^ 1], cnt_out);
+                if ((rc = t_end(5)) != RT_OK) return rc;
+                bn.mixed = true;
+                extend_done = true;
+            } else if (ns_ub > 0) {
+                if ((rc = t_begin(3)) != RT_OK) return rc;
+                launch_shadow(rt_trace_grid(ns_ub), cnt_out);
+                if ((rc = t_end(3)) != RT_OK) return rc;
+                bn.shadow = true;
+            }
+            n_ub = nn_ub;
+            cur ^= 1;
+            ++k;
+        }
+        // ---- what was traced, from the counts of every bounce (all arrived by now or after this wait)
+        uint32_t iter = 0;
+        for (size_t b = 0; b < hist.size(); ++b) {
+            if ((rc = wait_counts(b)) != RT_OK) return rc;
+            const uint32_t n_b = b > 0 ? hist[b - 1].n_next : n_paths;  // paths alive at bounce b
+            if (hist[b].n_next > n_b || hist[b].n_shadow > n_b) {
                 rth::set_error("rt_render: compaction produced impossible counts");
                 return RT_ERR_HIP;
             }
-            const bool tail_next = use_tail && n_next <= tail_paths;  // the tail kernel traces its own first ray
-            if (use_mix && n_shadow > 0 && n_next > 0 && !tail_next && (uint64_t)n_shadow + n_next <= mix_paths) {
-                // the shadow rays of this bounce and the rays of the next one in one launch
-                const uint32_t n_mix = n_shadow + n_next;
-                const int mgrid = (int)std::min<uint32_t>((n_mix + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
-                if ((rc = t_begin(5)) != RT_OK) return rc;
-                if (count == rtd::COUNT_REFERENCE)
-                    hipLaunchKernelGGL(k_mixed<rtd::COUNT_REFERENCE>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                       pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
-                                       rt_trace_tune(n_mix, mgrid), overflow, ostride);
-                else if (count == rtd::COUNT_FETCHES)
-                    hipLaunchKernelGGL(k_mixed<rtd::COUNT_FETCHES>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                       pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
-                                       rt_trace_tune(n_mix, mgrid), overflow, ostride);
-                else if (lean)
-                    hipLaunchKernelGGL(k_mixed_lean, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                       pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
-                                       rt_trace_tune(n_mix, mgrid), overflow, ostride);
-                else
-                    hipLaunchKernelGGL(k_mixed<rtd::COUNT_NONE>, dim3(mgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                       pa.queue[cur ^ 1], n_shadow, n_mix, pa.work + rtd::WORK_U32,
-                                       rt_trace_tune(n_mix, mgrid), overflow, ostride);
-                if ((rc = t_end(5)) != RT_OK) return rc;
-                st.rays_shadow += n_shadow;
-                st.rays_closest += n_next;
-                mixed_closest += n_next;
-                mixed_shadow += n_shadow;
+            if (n_b == 0) continue;  // a bounce enqueued on a stale bound after the last path had died
+            iter += 1;
+            if (hist[b].extend) {
+                st.rays_closest += n_b;
+                st.launches_extend += 1;
+            }
+            if (hist[b].mixed) {
+                st.rays_shadow += hist[b].n_shadow;
+                st.rays_closest += hist[b].n_next;
+                mixed_closest += hist[b].n_next;
+                mixed_shadow += hist[b].n_shadow;
                 st.launches_tail += 1;
-                extend_done = true;
-            } else if (n_shadow > 0) {
-                const int sgrid = (int)std::min<uint32_t>((n_shadow + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)trace_grid_max);
-                if ((rc = t_begin(3)) != RT_OK) return rc;
-                if (count == rtd::COUNT_REFERENCE)
-                    hipLaunchKernelGGL(k_shadow<rtd::COUNT_REFERENCE>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
-                                       pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
-                else if (count == rtd::COUNT_FETCHES)
-                    hipLaunchKernelGGL(k_shadow<rtd::COUNT_FETCHES>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
-                                       pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
-                else if (lean)
-                    hipLaunchKernelGGL(k_shadow_lean, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, n_shadow,
-                                       pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
-                else
-                    hipLaunchKernelGGL(k_shadow<rtd::COUNT_NONE>, dim3(sgrid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa,
-                                       n_shadow, pa.work + rtd::WORK_U32, rt_trace_tune(n_shadow, sgrid), overflow, ostride);
-                if ((rc = t_end(3)) != RT_OK) return rc;
-                st.rays_shadow += n_shadow;
+            } else if (hist[b].shadow && hist[b].n_shadow > 0) {
+                st.rays_shadow += hist[b].n_shadow;
                 st.launches_shadow += 1;
             }
-            n = n_next;
-            cur ^= 1;
-            ++iter;
         }
+        iter += tail_iters_total;
         if (iter > st.iterations) st.iterations = iter;
         hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, stream, pa, d_sum, npix, s_count,
                            first_batch ? 1 : 0);
@@ -1081,17 +1183,19 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     st.tris_tested = visit[1] + tail[3];
     st.nodes_visited_shadow = visit[2] + tail[4];
     st.tris_tested_shadow = visit[3] + tail[5];
-    st.ms_tail = tm[5].ms;
+    st.ms_tail = stage_ms[5];
     st.lean_kernels = lean ? 1u : 0u;
     st.nodes_visited_shadow_tail = tail[4];
     st.tris_tested_shadow_tail = tail[5];
-    st.ms_generate = tm[0].ms;
-    st.ms_extend = tm[1].ms;
-    st.ms_shade = tm[2].ms;
-    st.ms_shadow = tm[3].ms;
-    st.ms_compact = tm[4].ms;
+    st.ms_generate = stage_ms[0];
+    st.ms_extend = stage_ms[1];
+    st.ms_shade = stage_ms[2];
+    st.ms_shadow = stage_ms[3];
+    st.ms_compact = stage_ms[4];
     if (stats) *stats = st;
     return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_render");
 }
 
 #if RT_TRACE_STATS
