@@ -37,7 +37,9 @@ struct PathArrays {      // SoA over slots
     float4* ray_o;       // origin.xyz, bits: current medium (int) << 1 | previous bounce was specular
     float4* ray_d;       // direction.xyz, prev_pdf
     float4* beta;        // throughput.xyz, bits: depth (u32; wraps like the reference's, path_integrator.rs:193)
-    float4* rad;         // radiance.xyz, -
+    float4* rad;         // radiance.xyz, -   ALWAYS indexed by the path's original slot (k_resolve sums it in sample order)
+    uint32_t* oid;       // original slot (= sample_in_batch * pixels + pixel: names the pixel, the sample and the rad
+                         // record) of the path in each slot of a DENSE region; null in the first region, where slot = id
     float4* hit_a;       // t, normal.xyz (normal of analytic surfaces only)
     uint2* hit_b;        // obj | front_face<<31 (RT_MISS = no hit), triangle slot of a mesh hit (normal: shade_path)
     float4* sh_d;        // shadow direction.xyz, - (the shadow ray starts at ray_o: the vertex just shaded)
@@ -66,6 +68,7 @@ struct RenderParams {
     uint32_t depth;
     uint32_t k0, k1;        // Philox key = seed
     uint32_t bounce;        // k_shade: RNG bounce index of this wavefront iteration (= iteration + 1)
+    uint32_t identity_queue;  // queue position i holds slot i (first bounce; every bounce after a moving compaction): no look-up
     uint32_t implicit_first;  // the first bounce's origin, throughput, depth and medium are the same for every
                               // path (camera origin, 1, rp.depth, initial medium): k_generate does not store
                               // them and the first extend / shade do not load them (64 B per path less traffic)
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
     }
     pa.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
     pa.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (!rp.implicit_first) pa.queue[0][slot] = slot;  // implicit: nobody looks the identity up
+    // no queue entry: the first bounce's queue is the identity and nobody looks it up (RenderParams::identity_queue)
 }
 
 // ---------------------------------------------------------------- extend
@@ -118,10 +121,11 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
     const uint32_t* queue;
     unsigned long long n_int, n_tri;
     bool first;       // first bounce with implicit state (RenderParams::implicit_first): every ray starts at the camera
+    bool identity;    // queue position = slot (first bounce, and after a moving compaction)
     float cam[3];     // ... whose origin travels by value (a pointer into the kernel arguments turns the load of the
                       // origin into a flat load of a selected address)
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // returns the path's slot: the ray's tag from here on
-        const uint32_t slot = first ? i : queue[i];  // first bounce: the queue is the identity (k_generate)
+        const uint32_t slot = identity ? i : queue[i];
         float4 d4 = pa.ray_d[slot];
         if (first) {  // uniform
             *o = v3(cam[0], cam[1], cam[2]);
@@ -145,9 +149,6 @@ struct ExtendIO {  // rays come from the live-path queue, hits go to the path's 
     }
     RT_DEV void emit_closest(uint32_t slot, bool got, const Visits& vis) {
         if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
-#if RT_DEBUG_COUNT_IMAGE  // diagnostics build: the red channel of the image is the path's closest-hit triangle-test count
-        ((float*)&pa.rad[slot])[3] += (float)vis.n_tri;
-#endif
         n_int += vis.n_int;
         n_tri += vis.n_tri;
     }
@@ -162,7 +163,7 @@ __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t*
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n = counts[0];
     const TraceTune tune = make_tune(base, n, gridDim.x);
-    ExtendIO io{pa, queue, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
+    ExtendIO io{pa, queue, 0ull, 0ull, (first & 1u) != 0u, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
     trace_loop<TRACE_CLOSEST, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                              lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
@@ -176,7 +177,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n = counts[0];
     const TraceTune tune = make_tune(base, n, gridDim.x);
-    ExtendIO io{pa, queue, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
+    ExtendIO io{pa, queue, 0ull, 0ull, (first & 1u) != 0u, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
     trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                                   lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
@@ -187,12 +188,13 @@ __global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const
 // wave waits for one round trip here, not for two in a row.
 RT_DEV void add_pending_nee(const PathArrays& pa, uint32_t slot) {
     const float4 c = pa.sh_c[slot];
-    float4 r = pa.rad[slot];
+    const uint32_t id = pa.oid ? pa.oid[slot] : slot;  // uniform: dense region or the first one
+    float4 r = pa.rad[id];
     const bool add = c.w != 0.0f;  // p_light > 0
     r.x = add ? r.x + c.x : r.x;
     r.y = add ? r.y + c.y : r.y;
     r.z = add ? r.z + c.z : r.z;
-    pa.rad[slot] = r;
+    pa.rad[id] = r;
 }
 
 struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds its pending NEE term
@@ -298,8 +300,9 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
     bool prev_specular = (mbits & 1u) != 0;
 
     depth -= 1;  // `while depth > 0 { depth -= 1;` (:150-151)
-    uint32_t pixel = slot % rp.npix;
-    Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + slot / rp.npix, bounce, 0u};
+    const uint32_t id = pa.oid ? pa.oid[slot] : slot;  // the path's original slot: pixel, sample, radiance record
+    uint32_t pixel = id % rp.npix;
+    Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + id / rp.npix, bounce, 0u};
 
     if (!have_hit) ha = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
     float t_hit = ha.x;  // T_MAX for a miss (:155)
@@ -319,7 +322,7 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         }
         if (light >= 0) {
             V3 emitted = ld3(sc.lights[light].intensity);
-            float4 r = pa.rad[slot];
+            float4 r = pa.rad[id];
             V3 add = mul_elemwise(beta, emitted);
             if (!prev_specular) {
                 float p_light = (1.0f / (float)sc.n_lights) * light_pdf(sc.lights[light], ro, rd);  // :162
@@ -329,7 +332,7 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
             r.x += add.x;
             r.y += add.y;
             r.z += add.z;
-            pa.rad[slot] = r;
+            pa.rad[id] = r;
             return 0;  // light terminates the path (:166)
         }
     }
@@ -343,12 +346,12 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         if (k == MI_NULL) {
             beta = beta * transmittance;
         } else if (k == MI_ABSORPTION) {
-            float4 r = pa.rad[slot];
+            float4 r = pa.rad[id];
             V3 add = mul_elemwise(beta, mi.emission);
             r.x += add.x;
             r.y += add.y;
             r.z += add.z;
-            pa.rad[slot] = r;
+            pa.rad[id] = r;
             return 0;
         } else {
             depth -= 1;  // u32, wraps at 0 exactly like the release-mode reference (:193)
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     uint32_t flags = 0;
     if (i < n) {
         // the first bounce's queue is the identity (k_generate): no look-up
-        flags = shade_path(sc, pa, rp, rp.implicit_first ? i : queue[i], rp.bounce);
+        flags = shade_path(sc, pa, rp, rp.identity_queue ? i : queue[i], rp.bounce);
         pa.qflags[i] = flags;
     }
     // block totals for the compaction scan (wave ballots)
@@ -462,8 +465,9 @@ struct TailIO {
     unsigned long long n_int, n_tri;                   // closest-hit visits (COUNT)
     unsigned long long n_int_sh, n_tri_sh;             // shadow visits (COUNT)
     bool alive_after;                                  // the path goes on after its pending shadow ray
+    bool identity;                                     // queue position = slot
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) {
-        const uint32_t slot = queue[i];
+        const uint32_t slot = identity ? i : queue[i];
         float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
@@ -499,9 +503,6 @@ struct TailIO {
         if (!was_any) {
             n_int += vis.n_int;
             n_tri += vis.n_tri;
-#if RT_DEBUG_COUNT_IMAGE
-            ((float*)&pa.rad[slot])[3] += (float)vis.n_tri;
-#endif
             if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
             const uint32_t flags = shade_path(*sc, pa, *rp, slot, rp->bounce + iters - 1u);
             alive_after = (flags & QF_ALIVE) != 0;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, Ren
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n = counts[0];
     const TraceTune tune = make_tune(base, n, gridDim.x);
-    TailIO io{pa, queue, &sc, &rp, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false};
+    TailIO io{pa, queue, &sc, &rp, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false, rp.identity_queue != 0u};
     trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                           lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     unsigned long long v[6] = {io.n_closest, io.n_shadow, io.n_int, io.n_tri, io.n_int_sh, io.n_tri_sh};
@@ -562,16 +563,27 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, Ren
 // queue, items [n_shadow, n_shadow + n_next) the live-path queue.  k_shade of bounce k+1 still runs after
 // both, so the order of additions into a path's radiance is unchanged.
 struct MixedIO {
-    PathArrays pa;
+    PathArrays ps;          // region the shadow rays of this bounce live in
+    PathArrays pa;          // region of the next bounce's rays (the same one unless the compaction moved the paths)
     const uint32_t* queue;  // live paths of the NEXT bounce
     uint32_t n_shadow;
+    bool identity;          // queue position = slot in `pa`
     unsigned long long n_int, n_tri, n_int_sh, n_tri_sh;
     static constexpr bool CONTINUES = false;  // a finished ray is finished: the lane takes a new one
     RT_DEV bool first_is_any(uint32_t i) const { return i < n_shadow; }
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {
         const bool sh = i < n_shadow;
-        const uint32_t slot = sh ? pa.shadow_q[i] : queue[i - n_shadow];
-        float4 o4 = pa.ray_o[slot], d4 = sh ? pa.sh_d[slot] : pa.ray_d[slot];
+        uint32_t slot;
+        float4 o4, d4;
+        if (sh) {
+            slot = ps.shadow_q[i];
+            o4 = ps.ray_o[slot];
+            d4 = ps.sh_d[slot];
+        } else {
+            slot = identity ? i - n_shadow : queue[i - n_shadow];
+            o4 = pa.ray_o[slot];
+            d4 = pa.ray_d[slot];
+        }
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
         return slot;
@@ -592,7 +604,7 @@ struct MixedIO {
             n_int_sh += vis.n_int;
             n_tri_sh += vis.n_tri;
             if (!occluded) {
-                add_pending_nee(pa, slot);
+                add_pending_nee(ps, slot);
             }
         } else {
             n_int += vis.n_int;
@@ -604,14 +616,14 @@ struct MixedIO {
 };
 
 template <int COUNT>
-__global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, const uint32_t* queue, const uint32_t* counts,
-                                      uint32_t* work_counter, TuneBase base, uint32_t* overflow,
+__global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays ps, PathArrays pa, const uint32_t* queue, const uint32_t* counts,
+                                      uint32_t identity, uint32_t* work_counter, TuneBase base, uint32_t* overflow,
                                       uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n_shadow = counts[1], n = n_shadow + counts[0];  // shadow rays of this bounce, then the rays of the next
     const TraceTune tune = make_tune(base, n, gridDim.x);
-    MixedIO io{pa, queue, n_shadow, 0ull, 0ull, 0ull, 0ull};
+    MixedIO io{ps, pa, queue, n_shadow, identity != 0u, 0ull, 0ull, 0ull, 0ull};
     trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                           lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     if (COUNT) {  // accounted with the tail kernel's share: rays traced outside k_extend / k_shadow
@@ -620,14 +632,14 @@ __global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, const uint32_t* 
     }
 }
 
-__global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays pa, const uint32_t* queue, const uint32_t* counts,
-                                                uint32_t* work_counter, TuneBase base, uint32_t* overflow,
+__global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays ps, PathArrays pa, const uint32_t* queue, const uint32_t* counts,
+                                                uint32_t identity, uint32_t* work_counter, TuneBase base, uint32_t* overflow,
                                                 uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n_shadow = counts[1], n = n_shadow + counts[0];
     const TraceTune tune = make_tune(base, n, gridDim.x);
-    MixedIO io{pa, queue, n_shadow, 0ull, 0ull, 0ull, 0ull};
+    MixedIO io{ps, pa, queue, n_shadow, identity != 0u, 0ull, 0ull, 0ull, 0ull};
     trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN,
                                                                          __builtin_inff(), lds_stack + threadIdx.x,
                                                                          overflow + gtid, overflow_stride);
@@ -711,8 +723,13 @@ __global__ __launch_bounds__(1024) void k_compact_scan_top(PathArrays pa, const 
 }
 
 // Stable scatter: position = block offset + waves before + rank inside the wave ballot.
-__global__ __launch_bounds__(SHADE_BLOCK) void k_compact_scatter(PathArrays pa, const uint32_t* queue,
-                                                                 uint32_t* next_queue, const uint32_t* counts, uint32_t identity) {
+// move != 0: a MOVING compaction -- the surviving paths' state (origin, direction, throughput and their w lanes) goes
+// to slot `position` of the dense region `dst` together with the path's original slot, and the next bounce's queue is
+// the identity.  Late bounces keep a fifth of the slots alive or less: every 16-byte record a kernel touched pulled a
+// 64-byte sector for it (k_shade: 106 ps per path at the third bounce against 38 ps at the second, profiles/r02).
+__global__ __launch_bounds__(SHADE_BLOCK) void k_compact_scatter(PathArrays pa, const uint32_t* queue, uint32_t* next_queue,
+                                                                 const uint32_t* counts, uint32_t identity, PathArrays dst,
+                                                                 uint32_t move) {
     __shared__ uint32_t wave_cnt[2][SHADE_BLOCK / 64];
     const uint32_t n = counts[0];
     if (blockIdx.x * SHADE_BLOCK >= n) return;
@@ -731,7 +748,16 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_compact_scatter(PathArrays pa, 
     if (flags & QF_ALIVE) {
         uint32_t pos = pa.group_off[blockIdx.x / SCAN_GROUP] + pa.block_off[blockIdx.x];
         for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[0][w];
-        next_queue[pos + (uint32_t)__popcll(alive & below)] = slot;
+        pos += (uint32_t)__popcll(alive & below);
+        if (move) {  // uniform
+            const float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot], b4 = pa.beta[slot];
+            dst.ray_o[pos] = o4;
+            dst.ray_d[pos] = d4;
+            dst.beta[pos] = b4;
+            dst.oid[pos] = pa.oid ? pa.oid[slot] : slot;
+        } else {
+            next_queue[pos] = slot;
+        }
     }
     if (flags & QF_SHADOW) {
         uint32_t pos = pa.group_off[pa.max_groups + blockIdx.x / SCAN_GROUP] + pa.block_off[pa.max_blocks + blockIdx.x];
@@ -754,9 +780,6 @@ __global__ __launch_bounds__(256) void k_resolve(PathArrays pa, float* rgb_sum, 
     }
     for (uint32_t s = 0; s < s_count; ++s) {
         float4 r = pa.rad[(size_t)s * npix + pixel];
-#if RT_DEBUG_COUNT_IMAGE
-        r.x = r.w;
-#endif
         cx += r.x;
         cy += r.y;
         cz += r.z;
@@ -809,13 +832,13 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     // ---- batch size: samples in flight at once.  Every wavefront iteration ends in a tail of
     // half-empty waves and a host round trip, so the batch is made as large as memory allows
     // (measured at 1080p/32 spp: 8 Mi paths 145 ms, 64 Mi paths 71 ms): by default up to 40 % of
-    // the free HBM, ~148 B per path slot.
+    // the free HBM, ~212 B per path slot (148 B + two dense regions of a quarter of the slots, 128 B each).
     uint64_t max_paths = ctx->max_paths_in_flight;
     if (max_paths == 0) {
         size_t free_b = 0, total_b = 0;
         RT_HIP(hipMemGetInfo(&free_b, &total_b));
         free_b += ctx->path_state.bytes;  // our own previous allocation is reusable
-        max_paths = (uint64_t)((double)free_b * 0.4 / 148.0);
+        max_paths = (uint64_t)((double)free_b * 0.4 / 212.0);
         if (max_paths < ((uint64_t)1 << 20)) max_paths = (uint64_t)1 << 20;
     }
     uint32_t s_batch = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
@@ -832,39 +855,54 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         return o;
     };
     const uint32_t max_groups = max_blocks / SCAN_GROUP + 1;
-    size_t o_ray_o = carve(P * 16), o_ray_d = carve(P * 16), o_beta = carve(P * 16), o_rad = carve(P * 16),
-           o_hit_a = carve(P * 16), o_hit_b = carve(P * 8), o_sh_d = carve(P * 16), o_sh_c = carve(P * 16), o_q0 = carve(P * 4), o_q1 = carve(P * 4),
-           o_sq = carve(P * 4), o_qf = carve(P * 4), o_bc = carve((size_t)max_blocks * 8),
-           o_bo = carve((size_t)max_blocks * 8), o_gt = carve((size_t)max_groups * 8),
-           o_go = carve((size_t)max_groups * 8), o_cnt = carve(256), o_vis = carve(256), o_tail = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
+    // Regions: 0 = one slot per (sample, pixel) of the batch; 1 and 2 = dense regions of a quarter of the slots, the
+    // targets of the moving compaction (ping-pong).  rad, the scan scratch, counts and work counters are shared.
+    const uint64_t Rcap = std::max<uint64_t>(P / 4, 1);
+    struct RegionOff {
+        size_t ray_o, ray_d, beta, hit_a, hit_b, sh_d, sh_c, q0, q1, sq, qf, oid;
+    } ro[3];
+    for (int r = 0; r < 3; ++r) {
+        const uint64_t cap = r == 0 ? P : Rcap;
+        ro[r].ray_o = carve(cap * 16), ro[r].ray_d = carve(cap * 16), ro[r].beta = carve(cap * 16), ro[r].hit_a = carve(cap * 16);
+        ro[r].hit_b = carve(cap * 8), ro[r].sh_d = carve(cap * 16), ro[r].sh_c = carve(cap * 16), ro[r].q0 = carve(cap * 4);
+        ro[r].q1 = carve(cap * 4), ro[r].sq = carve(cap * 4), ro[r].qf = carve(cap * 4), ro[r].oid = r == 0 ? 0 : carve(cap * 4);
+    }
+    size_t o_rad = carve(P * 16), o_bc = carve((size_t)max_blocks * 8), o_bo = carve((size_t)max_blocks * 8),
+           o_gt = carve((size_t)max_groups * 8), o_go = carve((size_t)max_groups * 8), o_cnt = carve(256), o_vis = carve(256),
+           o_tail = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
     int rc = ctx->path_state.ensure(off);
     if (rc != RT_OK) return rc;
     if ((rc = rt_ctx_ensure_readback(ctx)) != RT_OK) return rc;
     char* base = (char*)ctx->path_state.p;
-    PathArrays pa;
-    pa.ray_o = (float4*)(base + o_ray_o);
-    pa.ray_d = (float4*)(base + o_ray_d);
-    pa.beta = (float4*)(base + o_beta);
-    pa.rad = (float4*)(base + o_rad);
-    pa.hit_a = (float4*)(base + o_hit_a);
-    pa.hit_b = (uint2*)(base + o_hit_b);
-    pa.sh_d = (float4*)(base + o_sh_d);
-    pa.sh_c = (float4*)(base + o_sh_c);
-    pa.queue[0] = (uint32_t*)(base + o_q0);
-    pa.queue[1] = (uint32_t*)(base + o_q1);
-    pa.shadow_q = (uint32_t*)(base + o_sq);
-    pa.qflags = (uint32_t*)(base + o_qf);
-    pa.block_cnt = (uint32_t*)(base + o_bc);
-    pa.block_off = (uint32_t*)(base + o_bo);
-    pa.group_tot = (uint32_t*)(base + o_gt);
-    pa.group_off = (uint32_t*)(base + o_go);
-    pa.counts = (uint32_t*)(base + o_cnt);
-    pa.counts_host = ctx->rb_host;
-    pa.max_blocks = max_blocks;
-    pa.max_groups = max_groups;
-    pa.work = (uint32_t*)(base + o_work);
-    pa.visit = (unsigned long long*)(base + o_vis);
-    pa.tail = (unsigned long long*)(base + o_tail);
+    PathArrays reg[3];
+    for (int r = 0; r < 3; ++r) {
+        PathArrays& q = reg[r];
+        q.ray_o = (float4*)(base + ro[r].ray_o);
+        q.ray_d = (float4*)(base + ro[r].ray_d);
+        q.beta = (float4*)(base + ro[r].beta);
+        q.rad = (float4*)(base + o_rad);
+        q.oid = r == 0 ? nullptr : (uint32_t*)(base + ro[r].oid);
+        q.hit_a = (float4*)(base + ro[r].hit_a);
+        q.hit_b = (uint2*)(base + ro[r].hit_b);
+        q.sh_d = (float4*)(base + ro[r].sh_d);
+        q.sh_c = (float4*)(base + ro[r].sh_c);
+        q.queue[0] = (uint32_t*)(base + ro[r].q0);
+        q.queue[1] = (uint32_t*)(base + ro[r].q1);
+        q.shadow_q = (uint32_t*)(base + ro[r].sq);
+        q.qflags = (uint32_t*)(base + ro[r].qf);
+        q.block_cnt = (uint32_t*)(base + o_bc);
+        q.block_off = (uint32_t*)(base + o_bo);
+        q.group_tot = (uint32_t*)(base + o_gt);
+        q.group_off = (uint32_t*)(base + o_go);
+        q.counts = (uint32_t*)(base + o_cnt);
+        q.counts_host = ctx->rb_host;
+        q.max_blocks = max_blocks;
+        q.max_groups = max_groups;
+        q.work = (uint32_t*)(base + o_work);
+        q.visit = (unsigned long long*)(base + o_vis);
+        q.tail = (unsigned long long*)(base + o_tail);
+    }
+    const PathArrays& pa = reg[0];  // what is not per region: rad, counts, work, visit, tail
     RT_HIP(hipMemsetAsync(pa.visit, 0, 256, stream));
     RT_HIP(hipMemsetAsync(pa.tail, 0, 256, stream));
 
@@ -901,6 +939,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         const char* e = getenv("RT_ASYNC_BELOW");  // without waiting for their exact counts (0: always wait)
         return e ? (uint32_t)strtoul(e, nullptr, 10) : (16u << 20);
     }();
+    const bool use_move = getenv("RT_NO_MOVE") == nullptr;  // moving compaction (k_compact_scatter)
     const bool timing = (flags & RT_RENDER_TIME_STAGES) != 0;
     // HIP events on the library's stream around every launch of a stage, summed per stage after the frame's last
     // synchronisation (the host runs ahead of the device, so a span cannot be read back where it is recorded).
@@ -962,7 +1001,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     uint32_t* const work_sh = pa.work + rtd::WORK_U32;    // shadow and mixed launches
 
     // kernel selection by counting mode / scene features, one place each
-    auto launch_extend = [&](int grid, const uint32_t* queue, const uint32_t* cnt, uint32_t first) {
+    auto launch_extend = [&](int grid, const PathArrays& pa, const uint32_t* queue, const uint32_t* cnt, uint32_t first) {
         if (count == rtd::COUNT_REFERENCE)
             hipLaunchKernelGGL(k_extend<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
@@ -972,7 +1011,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         else
             hipLaunchKernelGGL(k_extend<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
     };
-    auto launch_shadow = [&](int grid, const uint32_t* cnt) {
+    auto launch_shadow = [&](int grid, const PathArrays& pa, const uint32_t* cnt) {
         if (count == rtd::COUNT_REFERENCE)
             hipLaunchKernelGGL(k_shadow<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
@@ -982,17 +1021,17 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         else
             hipLaunchKernelGGL(k_shadow<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
     };
-    auto launch_mixed = [&](int grid, const uint32_t* queue_next, const uint32_t* cnt) {
+    auto launch_mixed = [&](int grid, const PathArrays& ps, const PathArrays& pa, const uint32_t* queue_next, uint32_t identity, const uint32_t* cnt) {
         if (count == rtd::COUNT_REFERENCE)
-            hipLaunchKernelGGL(k_mixed<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue_next, cnt, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_mixed<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
-            hipLaunchKernelGGL(k_mixed<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue_next, cnt, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_mixed<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
         else if (lean)
-            hipLaunchKernelGGL(k_mixed_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue_next, cnt, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_mixed_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
         else
-            hipLaunchKernelGGL(k_mixed<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue_next, cnt, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_mixed<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
     };
-    auto launch_tail = [&](int grid, const uint32_t* queue, const uint32_t* cnt) {
+    auto launch_tail = [&](int grid, const PathArrays& pa, const uint32_t* queue, const uint32_t* cnt) {
         if (count == rtd::COUNT_REFERENCE)
             hipLaunchKernelGGL(k_tail<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp, queue, cnt, work_ext, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
@@ -1028,9 +1067,11 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         // every path's state from memory)
         const bool implicit = depth > 0 && !(use_tail && n_paths <= tail_paths) && getenv("RT_NO_IMPLICIT") == nullptr;
         rp.implicit_first = implicit ? 1u : 0u;
+        rp.identity_queue = 1u;
+        rp.bounce = 0u;
         RT_HIP(hipMemsetAsync(pa.work, 0, 2 * rtd::WORK_U32 * 4, stream));
         if ((rc = t_begin(0)) != RT_OK) return rc;
-        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, pa, rp, n_paths);
+        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, reg[0], rp, n_paths);
         if ((rc = t_end(0)) != RT_OK) return rc;
         st.paths += n_paths;
         st.batches += 1;
@@ -1044,7 +1085,9 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         // from every late bounce (0.1 ms each, profiles/r02/tuning.md).
         hist.clear();
         uint32_t n_ub = depth > 0 ? n_paths : 0;
-        int cur = 0;
+        int rcur = 0;               // region the live paths are in
+        int cur = 0;                // which of the region's two queues holds them ...
+        bool ident = true;          // ... unless queue position = slot (first bounce, after a moving compaction)
         size_t k = 0;
         uint32_t tail_iters_total = 0;
         bool extend_done = false;  // the rays of this bounce were traced by the previous bounce's mixed launch
@@ -1053,15 +1096,17 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                 rth::set_error("rt_render: wavefront did not drain after 2^20 iterations");
                 return RT_ERR_LIMIT;
             }
+            const PathArrays& pr = reg[rcur];
             const uint32_t* cnt_in = pa.counts + 4 * (k & 1);
             uint32_t* cnt_out = pa.counts + 4 * ((k + 1) & 1);
             rp.bounce = (uint32_t)k + 1;  // iteration k of `while depth > 0` draws from RNG bounce k+1 (bounce 0: camera jitter)
             const uint32_t first_implicit = (implicit && k == 0) ? 1u : 0u;
             rp.implicit_first = first_implicit;
+            rp.identity_queue = ident ? 1u : 0u;
             if (use_tail && n_ub <= tail_paths) {  // few paths left: one launch takes them to their end
                 RT_HIP(hipMemsetAsync(pa.tail + 6, 0, 8, stream));
                 if ((rc = t_begin(5)) != RT_OK) return rc;
-                launch_tail(rt_trace_grid(n_ub), pa.queue[cur], cnt_in);
+                launch_tail(rt_trace_grid(n_ub), pr, pr.queue[cur], cnt_in);
                 if ((rc = t_end(5)) != RT_OK) return rc;
                 unsigned long long tail_iters = 0;
                 RT_HIP(hipMemcpyAsync(&tail_iters, pa.tail + 6, 8, hipMemcpyDeviceToHost, stream));
@@ -1076,27 +1121,24 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                 break;
             }
             hist.emplace_back();
-            Bounce& bn = hist.back();
             if (!extend_done) {
                 if ((rc = t_begin(1)) != RT_OK) return rc;
-                launch_extend(rt_trace_grid(n_ub), pa.queue[cur], cnt_in, first_implicit);
+                launch_extend(rt_trace_grid(n_ub), pr, pr.queue[cur], cnt_in, first_implicit ? 1u : (ident ? 2u : 0u));
                 if ((rc = t_end(1)) != RT_OK) return rc;
-                bn.extend = true;
+                hist[k].extend = true;
             }
             extend_done = false;
 
             const uint32_t n_blocks = (n_ub + SHADE_BLOCK - 1) / SHADE_BLOCK;
             if ((rc = t_begin(2)) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pa, rp, pa.queue[cur], cnt_in);
+            hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pr, rp, pr.queue[cur], cnt_in);
             if ((rc = t_end(2)) != RT_OK) return rc;
 
             if ((rc = t_begin(4)) != RT_OK) return rc;
             const uint32_t n_groups = (n_blocks + SCAN_GROUP - 1) / SCAN_GROUP;
-            hipLaunchKernelGGL(k_compact_scan_groups, dim3(n_groups), dim3(1024), 0, stream, pa, cnt_in);
-            hipLaunchKernelGGL(k_compact_scan_top, dim3(1), dim3(1024), 0, stream, pa, cnt_in, cnt_out,
+            hipLaunchKernelGGL(k_compact_scan_groups, dim3(n_groups), dim3(1024), 0, stream, pr, cnt_in);
+            hipLaunchKernelGGL(k_compact_scan_top, dim3(1), dim3(1024), 0, stream, pr, cnt_in, cnt_out,
                                ctx->rb_host + 4 * (k % RT_READBACK_RING));
-            hipLaunchKernelGGL(k_compact_scatter, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, pa, pa.queue[cur],
-                               pa.queue[cur ^ 1], cnt_in, first_implicit);
             if ((rc = t_end(4)) != RT_OK) return rc;
             RT_HIP(hipEventRecord(ctx->rb_ev[k % RT_READBACK_RING], stream));
 
@@ -1104,8 +1146,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             uint32_t nn_ub, ns_ub;
             if (n_ub > async_below) {  // big bounce: wait for its exact counts
                 if ((rc = wait_counts(k)) != RT_OK) return rc;
-                nn_ub = bn.n_next;
-                ns_ub = bn.n_shadow;
+                nn_ub = hist[k].n_next;
+                ns_ub = hist[k].n_shadow;
                 if (nn_ub > n_ub || ns_ub > n_ub) {
                     rth::set_error("rt_render: compaction produced impossible counts");
                     return RT_ERR_HIP;
@@ -1114,22 +1156,39 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                 if (k > 0 && (rc = wait_counts(k - 1)) != RT_OK) return rc;
                 nn_ub = ns_ub = k > 0 ? std::min(n_ub, hist[k - 1].n_next) : n_ub;
             }
+            // moving compaction: the survivors' state goes to a dense region as soon as one can hold them
+            const bool move = use_move && nn_ub > 0 && nn_ub <= Rcap;
+            const int rnext = move ? (rcur == 1 ? 2 : 1) : rcur;
+            const PathArrays& pn = reg[rnext];
+            if ((rc = t_begin(4)) != RT_OK) return rc;
+            hipLaunchKernelGGL(k_compact_scatter, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, pr, pr.queue[cur],
+                               pr.queue[cur ^ 1], cnt_in, ident ? 1u : 0u, pn, move ? 1u : 0u);
+            if ((rc = t_end(4)) != RT_OK) return rc;
+            const uint32_t* queue_next = move ? pn.queue[0] : pr.queue[cur ^ 1];
+
             const bool tail_next = use_tail && nn_ub <= tail_paths;  // the tail kernel traces its own first ray
             if (use_mix && ns_ub > 0 && nn_ub > 0 && !tail_next && (uint64_t)ns_ub + nn_ub <= mix_paths) {
                 // the shadow rays of this bounce and the rays of the next one in one launch
                 if ((rc = t_begin(5)) != RT_OK) return rc;
-                launch_mixed(rt_trace_grid((size_t)ns_ub + nn_ub), pa.queue[cur ^ 1], cnt_out);
+                launch_mixed(rt_trace_grid((size_t)ns_ub + nn_ub), pr, pn, queue_next, move ? 1u : 0u, cnt_out);
                 if ((rc = t_end(5)) != RT_OK) return rc;
-                bn.mixed = true;
+                hist[k].mixed = true;
                 extend_done = true;
             } else if (ns_ub > 0) {
                 if ((rc = t_begin(3)) != RT_OK) return rc;
-                launch_shadow(rt_trace_grid(ns_ub), cnt_out);
+                launch_shadow(rt_trace_grid(ns_ub), pr, cnt_out);
                 if ((rc = t_end(3)) != RT_OK) return rc;
-                bn.shadow = true;
+                hist[k].shadow = true;
             }
             n_ub = nn_ub;
-            cur ^= 1;
+            rcur = rnext;
+            if (move) {
+                cur = 0;
+                ident = true;
+            } else {
+                cur ^= 1;
+                ident = false;
+            }
             ++k;
         }
         // ---- what was traced, from the counts of every bounce (all arrived by now or after this wait)
