@@ -1,11 +1,15 @@
 """Per-kernel HBM traffic of one rendered frame from the rocprofv3 --pmc passes of scripts/pmc_traffic.sh."""
 import collections, csv, glob, json, os, re, sys
 d = sys.argv[1]
+wl = sys.argv[2] if len(sys.argv) > 2 else "render"
+width = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
+spp = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+build = sys.argv[5] if len(sys.argv) > 5 else None
 agg = collections.defaultdict(float)
 calls = collections.defaultdict(set)
 for f in glob.glob(os.path.join(d, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_[a-z_]+)", r["Kernel_Name"])
+        m = re.search(r"(k_[a-z_]+(<[0-9]>)?)", r["Kernel_Name"])
         if not m:
             continue
         k = m.group(1)
@@ -22,7 +26,8 @@ for k in sorted({k for k, _ in agg}):
                   "hbm_bytes_per_launch": (fetch + write) / n,
                   "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
 print(json.dumps({
-    "workload": {"name": "render", "levels": 9, "width": 1920, "spp": 64, "depth": 16},
+    "workload": {"name": "config5" if wl.startswith("config5") else wl, "instanced": wl == "config5i", "levels": 9, "width": width, "spp": spp, "depth": 16},
+    "build": build,
     "note": "FETCH_SIZE doubled per the gfx950 correction; the counter sits on the fabric side of L2 and also counts "
             "Infinity-Cache hits, so this is an upper bound on HBM bytes. One frame = scripts/prof_render.py 64.",
     "kernels": kernels}, indent=1))
