@@ -222,7 +222,7 @@ def main():
         # one more (untimed) step with HIP events around every stage, for the breakdown in `detail`
         step(False, all_stages=True)
         st = last["st"]
-        rays_per_step = st.rays_closest + st.rays_shadow
+        rays_per_step = st.rays_closest + st.rays_shadow - st.rays_shadow_skipped  # rays actually traced
 
         def alg_bytes(c, ext):  # 48 + 64 N_int + 40 N_tri per ray of the extend / of the mixed+tail launches
             if ext:
@@ -260,6 +260,7 @@ def main():
                       n_tri_mean=st_count.tris_tested / max(1, st_count.rays_closest),
                       n_int_reference=st_ref.nodes_visited / max(1, st_ref.rays_closest),
                       rays_closest=int(st.rays_closest), rays_shadow=int(st.rays_shadow),
+                      rays_shadow_not_traced=int(st.rays_shadow_skipped),
                       iterations=int(st.iterations), spp_this_rank=int(spp_count), reduce=reduce_kind)
         if args.workload == "config5":
             workload = (f"configs[4] scene: plane + {args.copies} subdivided tetrahedra, "

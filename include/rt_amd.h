@@ -283,7 +283,8 @@ int rt_trace_closest_noalloc(rt_ctx* ctx, const rt_rays* rays, size_t n, float t
 
 typedef struct rt_stats {
     uint64_t rays_closest;  /* Engine::hit calls issued (extend kernel lanes) */
-    uint64_t rays_shadow;   /* Engine::hit_bool calls issued (shadow-connect lanes) */
+    uint64_t rays_shadow;   /* Engine::hit_bool calls the reference's algorithm issues (= the oracle's count); of these,
+                               rays_shadow_skipped were not traced (below) */
     uint64_t paths;         /* camera paths started = width*height*spp_count */
     uint64_t nodes_visited; /* sum of n_int over the closest-hit rays (only with RT_RENDER_COUNT_VISITS) */
     uint64_t tris_tested;   /* sum of n_tri over the closest-hit rays (only with RT_RENDER_COUNT_VISITS) */
@@ -305,6 +306,11 @@ typedef struct rt_stats {
     float ms_tail;            /* always filled, like ms_extend */
     uint32_t lean_kernels;    /* 1: the scene has no analytic sphere/triangle objects and the lean traversal kernels (k_*_lean) ran */
     uint64_t nodes_visited_shadow_tail, tris_tested_shadow_tail; /* shadow rays of the mixed / tail launches */
+    /* Shadow rays the reference traces (path_integrator.rs:219) whose light term is exactly zero or never added
+       (p_light = 0, :230): whatever they hit, no bit of the radiance depends on it, so rt_render does not trace
+       them.  Counted in rays_shadow, not traced.  Always 0 with RT_RENDER_COUNT_VISITS (every ray is traced so
+       that the visit counters equal the oracle's). */
+    uint64_t rays_shadow_skipped;
 } rt_stats;
 
 #define RT_RENDER_COUNT_VISITS 1u /* fill nodes_visited / tris_tested with the REFERENCE's visits: no root-box

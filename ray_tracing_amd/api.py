@@ -113,7 +113,8 @@ class Stats(C.Structure):
                 ("paths_tail", C.c_uint64), ("rays_closest_tail", C.c_uint64), ("rays_shadow_tail", C.c_uint64),
                 ("nodes_visited_tail", C.c_uint64), ("tris_tested_tail", C.c_uint64), ("launches_tail", C.c_uint64),
                 ("ms_tail", C.c_float), ("lean_kernels", C.c_uint32),
-                ("nodes_visited_shadow_tail", C.c_uint64), ("tris_tested_shadow_tail", C.c_uint64)]
+                ("nodes_visited_shadow_tail", C.c_uint64), ("tris_tested_shadow_tail", C.c_uint64),
+                ("rays_shadow_skipped", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

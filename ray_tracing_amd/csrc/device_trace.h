@@ -23,7 +23,7 @@
 namespace rtd {
 
 #if RT_TRACE_STATS  // diagnostics build only (scripts/build_variant.sh stats -DRT_TRACE_STATS=1)
-static __device__ unsigned long long g_trace_stats[32];
+static __device__ unsigned long long g_trace_stats[40];
 #define RT_STAT(i, v) s_stat[i] += (v)
 #else
 #define RT_STAT(i, v)
@@ -146,6 +146,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     Visits vis = {0, 0};
 #if RT_TRACE_STATS
     unsigned long long s_stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long s_uni[4] = {0, 0, 0, 0};  // node steps, steps with one node for all lanes, lanes on the first lane's node, lanes
     unsigned long long s_cyc[5] = {0, 0, 0, 0, 0};  // wave cycles in: scheduler+refill, advance, node, leaf, (total)
     unsigned long long t_mark = __builtin_readcyclecounter();
     const unsigned long long t_start = t_mark;
@@ -440,6 +441,19 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             // remaining repetitions.  1 / 2 / 3 / 4 / 6 repetitions: extend 34.4 / 32.5 / 32.1 / 32.0 / 32.5 ms.
             for (int rep = 0; rep < RT_NODE_REPS; ++rep)
             if (ray != RAY_NONE && (cur & LEAF_BIT) == 0u) {
+#if RT_TRACE_STATS  // how often do all lanes of a node step visit the SAME node (candidates for one scalar fetch)?
+                {
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+                    const unsigned long long same = __builtin_amdgcn_ballot_w64(cur == c0);
+                    if (lane == (uint32_t)__builtin_ctzll(act)) {
+                        s_uni[0] += 1;
+                        s_uni[1] += same == act ? 1 : 0;
+                        s_uni[2] += (unsigned long long)__popcll(same);
+                        s_uni[3] += (unsigned long long)__popcll(act);
+                    }
+                }
+#endif
                 const uint32_t off = cur << 6;
                 float4 a0 = ld16(sc.pairs, off), a1 = ld16(sc.pairs, off + 16u), b0 = ld16(sc.pairs, off + 32u),
                        b1 = ld16(sc.pairs, off + 48u);
@@ -495,6 +509,8 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         s_cyc[4] = __builtin_readcyclecounter() - t_start;
         for (int i = 0; i < 5; ++i) atomicAdd(&g_trace_stats[(MODE == TRACE_ANY ? 24 : 16) + i], s_cyc[i]);
     }
+    for (int i = 0; i < 4; ++i)
+        if (s_uni[i]) atomicAdd(&g_trace_stats[32 + (MODE == TRACE_ANY ? 4 : 0) + i], s_uni[i]);
 #endif
 }
 

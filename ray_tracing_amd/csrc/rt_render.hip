@@ -29,7 +29,7 @@ namespace {
 constexpr float T_MIN = 1e-3f;  // path_integrator.rs:15
 constexpr int SHADE_BLOCK = 256;
 
-constexpr uint32_t QF_ALIVE = 1u, QF_SHADOW = 2u;
+constexpr uint32_t QF_ALIVE = 1u, QF_SHADOW = 2u, QF_SKIPPED = 4u;  // QF_SKIPPED: a shadow ray the reference issues and nobody needs
 
 struct PathArrays {      // SoA over slots
     // 16-byte records; the w lanes carry the scalar path state, so a bounce moves 3 records per path
@@ -70,6 +70,7 @@ struct RenderParams {
     uint32_t depth;
     uint32_t k0, k1;        // Philox key = seed
     uint32_t bounce;        // k_shade: RNG bounce index of this wavefront iteration (= iteration + 1)
+    uint32_t skip_zero_nee;   // do not trace shadow rays whose light term is exactly zero (not when counting the reference's visits)
     uint32_t identity_queue;  // queue position i holds slot i (first bounce; every bounce after a moving compaction): no look-up
     uint32_t implicit_first;  // the first bounce's origin, throughput, depth and medium are the same for every
                               // path (camera origin, 1, rp.depth, initial medium): k_generate does not store
@@ -409,9 +410,20 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         float p_bsdf = bsdf_pdf(mat, wi_local, wo_local);
         float w = mis_weight(p_light, p_bsdf);
         V3 add = (w * mul_elemwise(beta, contribution)) / p_light;
-        pa.sh_d[slot] = make_float4(ls.direction.x, ls.direction.y, ls.direction.z, 0.0f);
-        pa.sh_c[slot] = make_float4(add.x, add.y, add.z, p_light > 0.0f ? 1.0f : 0.0f);
-        flags |= QF_SHADOW;
+        // The reference traces the shadow ray first and evaluates the term afterwards (:219-236).  With the term in
+        // hand, a term that cannot change a bit of the radiance needs no ray: p_light = 0 (never added, :230) or
+        // exactly (+-0, +-0, +-0) (r + 0 = r; the radiance starts at +0 and sums of non-negative-zero terms never
+        // reach -0; a NaN term is not zero and is traced).  4.4 % of the bench frame's shadow rays -- the light
+        // behind the surface, Diffuse::eval = 0 -- and its longest ones: they start on the far side of the mesh and
+        // run through it (frame 58.6 -> 53.9 ms, same bits).
+        const bool useless = rp.skip_zero_nee && (!(p_light > 0.0f) || (add.x == 0.0f && add.y == 0.0f && add.z == 0.0f));
+        if (!useless) {
+            pa.sh_d[slot] = make_float4(ls.direction.x, ls.direction.y, ls.direction.z, 0.0f);
+            pa.sh_c[slot] = make_float4(add.x, add.y, add.z, p_light > 0.0f ? 1.0f : 0.0f);
+            flags |= QF_SHADOW;
+        } else {
+            flags |= QF_SKIPPED;
+        }
     }
 
     // throughput and next ray (:241-250)
@@ -440,7 +452,7 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
 
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa, RenderParams rp,
                                                        const uint32_t* queue, const uint32_t* counts) {
-    __shared__ uint32_t wave_cnt[2][SHADE_BLOCK / 64];
+    __shared__ uint32_t wave_cnt[3][SHADE_BLOCK / 64];
     const uint32_t n = counts[0];
     if (blockIdx.x * SHADE_BLOCK >= n) return;  // the grid is sized from an upper bound of n (uniform per block)
     uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
@@ -453,13 +465,15 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     // block totals for the compaction scan (wave ballots)
     unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
     unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
+    unsigned long long skipped = __ballot((flags & QF_SKIPPED) != 0);
     uint32_t wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         wave_cnt[0][wave] = (uint32_t)__popcll(alive);
         wave_cnt[1][wave] = (uint32_t)__popcll(shadow);
+        wave_cnt[2][wave] = (uint32_t)__popcll(skipped);
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 3) {
         uint32_t s = 0;
         for (int w = 0; w < SHADE_BLOCK / 64; ++w) s += wave_cnt[threadIdx.x][w];
         pa.block_cnt[threadIdx.x * pa.max_blocks + blockIdx.x] = s;
@@ -483,7 +497,7 @@ struct TailIO {
     const uint32_t* queue;
     const DScene* sc;
     const RenderParams* rp;
-    uint32_t n_closest, n_shadow, iters, max_iters;  // per lane
+    uint32_t n_closest, n_shadow, n_skipped, iters, max_iters;  // per lane
     unsigned long long n_int, n_tri;                   // closest-hit visits (COUNT)
     unsigned long long n_int_sh, n_tri_sh;             // shadow visits (COUNT)
     bool alive_after;                                  // the path goes on after its pending shadow ray
@@ -528,6 +542,7 @@ struct TailIO {
             if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
             const uint32_t flags = shade_path(*sc, pa, *rp, slot, rp->bounce + iters - 1u);
             alive_after = (flags & QF_ALIVE) != 0;
+            if (flags & QF_SKIPPED) n_skipped += 1;
             if (flags & QF_SHADOW) {
                 float4 o4 = pa.ray_o[slot], d4 = pa.sh_d[slot];
                 *o = v3(o4.x, o4.y, o4.z);
@@ -552,7 +567,7 @@ RT_DEV unsigned long long wave_sum_u64(unsigned long long v) {
     return v;
 }
 
-// pa.tail[0..7]: closest rays, shadow rays, n_int, n_tri (closest), n_int, n_tri (shadow), max iterations, unused
+// pa.tail[0..7]: closest rays, shadow rays, n_int, n_tri (closest), n_int, n_tri (shadow), max iterations, shadow rays not needed
 template <int COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, RenderParams rp, const uint32_t* queue,
                                                    const uint32_t* counts, uint32_t* work_counter, TuneBase base,
@@ -561,17 +576,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, Ren
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n = counts[0];
     const TraceTune tune = make_tune(base, n, gridDim.x);
-    TailIO io{pa, queue, &sc, &rp, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false, rp.identity_queue != 0u};
+    TailIO io{pa, queue, &sc, &rp, 0u, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false, rp.identity_queue != 0u};
     trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                           lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
     unsigned long long v[6] = {io.n_closest, io.n_shadow, io.n_int, io.n_tri, io.n_int_sh, io.n_tri_sh};
     uint32_t mx = io.max_iters;
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
     for (int k = 0; k < 6; ++k) v[k] = wave_sum_u64(v[k]);
+    const unsigned long long sk = wave_sum_u64(io.n_skipped);
     if ((threadIdx.x & 63) == 0) {
         for (int k = 0; k < 6; ++k)
             if (v[k]) atomicAdd(&pa.tail[k], v[k]);
         atomicMax(&pa.tail[6], (unsigned long long)mx);
+        if (sk) atomicAdd(&pa.tail[7], sk);
     }
 }
 
@@ -700,18 +717,18 @@ RT_DEV uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wave_sum /*[16]*/, ui
 }
 
 __global__ __launch_bounds__(1024) void k_compact_scan_groups(PathArrays pa, const uint32_t* counts) {
-    __shared__ uint32_t wave_sum[2][16];
-    __shared__ uint32_t total[2];
+    __shared__ uint32_t wave_sum[3][16];
+    __shared__ uint32_t total[3];
     const uint32_t n = counts[0];
     const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
     if (blockIdx.x * SCAN_GROUP >= n_blocks) return;  // grid sized from an upper bound of n
     const uint32_t b = blockIdx.x * SCAN_GROUP + threadIdx.x;
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 3; ++q) {  // alive, shadow, skipped (a total only: nothing is scattered for it)
         const uint32_t v = b < n_blocks ? pa.block_cnt[q * pa.max_blocks + b] : 0u;
         const uint32_t e = block_excl_scan_1024(v, wave_sum[q], &total[q]);
-        if (b < n_blocks) pa.block_off[q * pa.max_blocks + b] = e;
+        if (q < 2 && b < n_blocks) pa.block_off[q * pa.max_blocks + b] = e;
     }
-    if (threadIdx.x < 2) pa.group_tot[threadIdx.x * pa.max_groups + blockIdx.x] = total[threadIdx.x];
+    if (threadIdx.x < 3) pa.group_tot[threadIdx.x * pa.max_groups + blockIdx.x] = total[threadIdx.x];
 }
 
 // One workgroup: scans the group totals, publishes the counts of the next bounce -- to device memory for the kernels
@@ -719,26 +736,26 @@ __global__ __launch_bounds__(1024) void k_compact_scan_groups(PathArrays pa, con
 // the work counters of the trace launches that follow.
 __global__ __launch_bounds__(1024) void k_compact_scan_top(PathArrays pa, const uint32_t* counts, uint32_t* counts_out,
                                                            uint32_t* counts_host) {
-    __shared__ uint32_t wave_sum[2][16];
-    __shared__ uint32_t total[2];
+    __shared__ uint32_t wave_sum[3][16];
+    __shared__ uint32_t total[3];
     const uint32_t n = counts[0];
     const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
     const uint32_t n_groups = (n_blocks + SCAN_GROUP - 1) / SCAN_GROUP;
     const uint32_t per = (n_groups + 1023u) / 1024u;  // <= 8
     const uint32_t begin = threadIdx.x * per, end = min(begin + per, n_groups);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 3; ++q) {
         uint32_t s = 0;
         for (uint32_t g = begin; g < end; ++g) s += pa.group_tot[q * pa.max_groups + g];
         uint32_t run = block_excl_scan_1024(s, wave_sum[q], &total[q]);
-        for (uint32_t g = begin; g < end; ++g) {
+        for (uint32_t g = begin; q < 2 && g < end; ++g) {
             const uint32_t c = pa.group_tot[q * pa.max_groups + g];
             pa.group_off[q * pa.max_groups + g] = run;
             run += c;
         }
     }
     for (uint32_t i = threadIdx.x; i < 2u * WORK_U32; i += 1024u) pa.work[i] = 0u;
-    if (threadIdx.x < 2) {
-        counts_out[threadIdx.x] = total[threadIdx.x];  // [0] paths alive after this bounce, [1] its shadow rays
+    if (threadIdx.x < 3) {
+        counts_out[threadIdx.x] = total[threadIdx.x];  // [0] paths alive after this bounce, [1] its shadow rays, [2] shadow rays not needed
         counts_host[threadIdx.x] = total[threadIdx.x];
         __threadfence_system();
     }
@@ -929,8 +946,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         ro[r].hit_b = carve(cap * 8), ro[r].sh_d = carve(cap * 16), ro[r].sh_c = carve(cap * 16), ro[r].q0 = carve(cap * 4);
         ro[r].q1 = carve(cap * 4), ro[r].sq = carve(cap * 4), ro[r].qf = carve(cap * 4), ro[r].oid = r == 0 ? 0 : carve(cap * 4);
     }
-    size_t o_rad = carve(P * 16), o_bc = carve((size_t)max_blocks * 8), o_bo = carve((size_t)max_blocks * 8),
-           o_gt = carve((size_t)max_groups * 8), o_go = carve((size_t)max_groups * 8), o_cnt = carve(256), o_vis = carve(256),
+    size_t o_rad = carve(P * 16), o_bc = carve((size_t)max_blocks * 12), o_bo = carve((size_t)max_blocks * 8),
+           o_gt = carve((size_t)max_groups * 12), o_go = carve((size_t)max_groups * 8), o_cnt = carve(256), o_vis = carve(256),
            o_tail = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
     int rc = ctx->path_state.ensure(off);
     if (rc != RT_OK) return rc;
@@ -1056,6 +1073,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     rp.height = height;
     rp.npix = npix;
     rp.pixel_major = getenv("RT_SAMPLE_MAJOR") == nullptr ? 1u : 0u;
+    rp.skip_zero_nee = (count != rtd::COUNT_REFERENCE && getenv("RT_TRACE_ZERO_NEE") == nullptr) ? 1u : 0u;
     rp.depth = depth;
     rp.k0 = (uint32_t)seed;
     rp.k1 = (uint32_t)(seed >> 32);
@@ -1107,7 +1125,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     // for it (read from pinned memory once the event recorded behind that kernel has completed).
     struct Bounce {
         bool extend = false, mixed = false, shadow = false, got = false;
-        uint32_t n_next = 0, n_shadow = 0;  // paths alive after the bounce, shadow rays of the bounce
+        uint32_t n_next = 0, n_shadow = 0, n_skipped = 0;  // paths alive after the bounce, its shadow rays traced / not needed
     };
     std::vector<Bounce> hist;
     auto wait_counts = [&](size_t k) -> int {
@@ -1116,6 +1134,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         const volatile uint32_t* h = ctx->rb_host + 4 * (k % RT_READBACK_RING);
         hist[k].n_next = h[0];
         hist[k].n_shadow = h[1];
+        hist[k].n_skipped = h[2];
         hist[k].got = true;
         return RT_OK;
     };
@@ -1266,6 +1285,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
             }
             if (n_b == 0) continue;  // a bounce enqueued on a stale bound after the last path had died
             iter += 1;
+            st.rays_shadow += hist[b].n_skipped;  // issued by the reference's algorithm, traced by nobody
+            st.rays_shadow_skipped += hist[b].n_skipped;
             if (hist[b].extend) {
                 st.rays_closest += n_b;
                 st.launches_extend += 1;
@@ -1305,7 +1326,8 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     st.nodes_visited_tail = tail[2];
     st.tris_tested_tail = tail[3];
     st.rays_closest += tail[0];
-    st.rays_shadow += tail[1];
+    st.rays_shadow += tail[1] + tail[7];
+    st.rays_shadow_skipped += tail[7];
     st.nodes_visited = visit[0] + tail[2];
     st.tris_tested = visit[1] + tail[3];
     st.nodes_visited_shadow = visit[2] + tail[4];
@@ -1334,9 +1356,9 @@ extern "C" int rt_debug_occupancy(int* out4) {  // resident workgroups per CU: e
     return 0;
 }
 extern "C" int rt_debug_trace_stats(unsigned long long* out32, int reset) {
-    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(rtd::g_trace_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(rtd::g_trace_stats), 40 * sizeof(unsigned long long)) != hipSuccess) return -2;
     if (reset) {
-        unsigned long long z[32] = {0};
+        unsigned long long z[40] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_stats), z, sizeof z) != hipSuccess) return -2;
     }
     return 0;
