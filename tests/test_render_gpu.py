@@ -37,10 +37,19 @@ def _check(ctx, desc, w, h, spp, depth, seed=0, spp_first=0, max_paths=None):
     assert st.nodes_visited + st.nodes_visited_shadow == ost.nodes_visited
     assert st.tris_tested + st.tris_tested_shadow == ost.tris_tested
     assert st.paths == w * h * spp
-    # the non-counting kernels give the same image
+    assert st.rays_shadow_skipped == 0  # counting the reference's visits: every shadow ray is traced
+    # the non-counting kernels give the same image -- without tracing the shadow rays whose light term is exactly zero
+    # (rays_shadow stays the reference's count of Engine::hit_bool calls)
     img2, st2 = ctx.render(w, h, spp, depth, seed, spp_first)
     assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32))
     assert (st2.rays_closest, st2.rays_shadow) == (ost.rays_closest, ost.rays_shadow)
+    assert st2.rays_shadow_skipped <= st2.rays_shadow
+    # the fetch-counting kernels are the timed ones with counters: same image, same skips, no more visits than the reference
+    img4, st4 = ctx.render(w, h, spp, depth, seed, spp_first, flags=rt.api.RENDER_COUNT_FETCHES)
+    assert np.array_equal(img4.view(np.uint32), ref.view(np.uint32))
+    assert st4.rays_shadow_skipped == st2.rays_shadow_skipped
+    assert st4.nodes_visited + st4.nodes_visited_shadow <= ost.nodes_visited
+    assert st4.tris_tested + st4.tris_tested_shadow <= ost.tris_tested
     # frames this small go to the tail kernel at once (every path alive <= its threshold); the pure
     # wavefront pipeline -- one launch per stage and bounce -- must give the same image and counters
     assert st.launches_tail >= 1 and st.paths_tail > 0
@@ -70,8 +79,13 @@ def test_mid_size_frame_takes_wavefront_mixed_and_tail_launches(ctx):
 
 
 def test_config3_scene_area_light_dielectric(ctx):
-    img, st, _ = _check(ctx, scenes.path_scene(levels=5, glass_levels=3), 96, 54, 4, 16, seed=3)
+    desc = scenes.path_scene(levels=5, glass_levels=3)
+    img, st, _ = _check(ctx, desc, 96, 54, 4, 16, seed=3)
     assert img.mean() > 0 and st.iterations > 4
+    # the diffuse mesh turns part of its surface away from the light: those shadow rays carry a zero term
+    for flags in (0, rt.api.RENDER_NO_TAIL):
+        _, st2 = ctx.render(96, 54, 4, 16, 3, flags=flags)
+        assert 0 < st2.rays_shadow_skipped < st2.rays_shadow // 4
 
 
 def test_config4_scene_homogeneous_medium(ctx):
