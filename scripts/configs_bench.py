@@ -16,7 +16,7 @@ def run(name, desc, w, spp, depth=16, reps=2):
         _, st = ctx.render(w, h, spp, depth, 0, 0, out=acc.data_ptr())
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    rays = st.rays_closest + st.rays_shadow
+    rays = st.rays_closest + st.rays_shadow - st.rays_shadow_skipped  # traced
     print(f"{name:34s} {scene.flat.n_tris:9d} tris {scene.flat.n_objects:3d} objects  {w}x{h} {spp:4d} spp  {best*1e3:9.1f} ms/frame "
           f"{rays/best/1e6:8.1f} Mrays/s  ({rays/1e6:.1f} M rays, {st.batches} batch(es), lean={st.lean_kernels}, scene build {t_build:.1f} s)", flush=True)
     ctx.close()
@@ -24,5 +24,9 @@ def run(name, desc, w, spp, depth=16, reps=2):
 run("config 1 volumetric sphere", scenes.volumetric_sphere(), 400, 256)
 run("config 3 path tracing", scenes.path_scene(levels=9), 1920, 64)
 run("config 4 + homogeneous medium", scenes.path_scene(levels=9, medium=True, sigma_s=0.02), 1920, 64)
-run("config 5 10 x 1M-triangle meshes", scenes.multi_mesh_scene(levels=9, copies=10), 1920, 64)
-run("config 5 at 3840x2160, 64 spp", scenes.multi_mesh_scene(levels=9, copies=10), 3840, 64, reps=1)
+run("config 2 scene, path traced", scenes.tetrahedron_scene(levels=9), 1920, 64)
+run("config 5 instanced (one BVH x10)", scenes.multi_mesh_scene(levels=9, copies=10), 1920, 64)
+run("config 5 ten distinct meshes", scenes.multi_mesh_scene(levels=9, copies=10, distinct=True), 1920, 64)
+run("config 5 instanced, 3840x2160", scenes.multi_mesh_scene(levels=9, copies=10), 3840, 64, reps=1)
+run("config 5 distinct, 3840x2160", scenes.multi_mesh_scene(levels=9, copies=10, distinct=True), 3840, 64, reps=1)
+run("config 5 distinct, 4K, 256 spp", scenes.multi_mesh_scene(levels=9, copies=10, distinct=True), 3840, 256, reps=1)
