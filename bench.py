@@ -172,15 +172,21 @@ def main():
         if use_dist:
             reduce_kind = "torch.distributed"
             if not args.torch_reduce:
-                try:
-                    uid = torch.zeros(rt.api.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-                    if rank == 0:
-                        uid = torch.tensor(list(rt.comm_unique_id()), dtype=torch.uint8, device=dev)
-                    dist.broadcast(uid, src=0)
-                    comm = rt.Comm(ctx, bytes(uid.cpu().tolist()), world, rank)
-                    reduce_kind = "rt_reduce_accum (RCCL, C ABI)"
-                except rt.RtError as e:  # plumbing fallback for the collective only; labelled in the output
-                    print(f"bench: rt_comm_create failed on rank {rank} ({e}); reducing with torch.distributed", file=sys.stderr)
+                # rank 0 creates the unique id; byte 128 says whether it could (every rank takes part in the broadcast either way)
+                uid = torch.zeros(rt.api.COMM_ID_BYTES + 1, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    try:
+                        uid = torch.tensor(list(rt.comm_unique_id()) + [1], dtype=torch.uint8, device=dev)
+                    except rt.RtError as e:
+                        print(f"bench: rt_comm_unique_id failed ({e}); reducing with torch.distributed", file=sys.stderr)
+                dist.broadcast(uid, src=0)
+                uid = uid.cpu().tolist()
+                if uid[-1] == 1:
+                    try:
+                        comm = rt.Comm(ctx, bytes(uid[:-1]), world, rank)
+                        reduce_kind = "rt_reduce_accum (RCCL, C ABI)"
+                    except rt.RtError as e:  # plumbing fallback for the collective only; labelled in the output
+                        print(f"bench: rt_comm_create failed on rank {rank} ({e}); reducing with torch.distributed", file=sys.stderr)
             ok = torch.tensor([1 if (comm is not None or args.torch_reduce) else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0 and comm is not None:  # some rank fell back: all ranks must
