@@ -86,6 +86,49 @@ def test_random_rays_and_t_range(ctx):
         assert np.array_equal(ga["n_tri"], oa["n_tri"])
 
 
+def test_degenerate_rays(ctx):
+    """Rays the slab and Moeller-Trumbore arithmetic meets at its edges: origins exactly on mesh vertices and edge
+    midpoints, directions along the axes (two zero components: 1/0 = inf, 0 * inf = NaN in the slab test, which
+    f32::max / min ignore, primitives.rs:313-314), exactly along triangle edges, un-normalised (the reference's own
+    AABB test uses such a ray, primitives.rs:358-366), zero, infinite and NaN.  Whatever the reference's arithmetic makes of
+    them, both kernels families (culling / counting) must make the same, bit for bit, and terminate."""
+    desc = scenes.path_scene(levels=4, glass_levels=3)  # a plain mesh, a scaled + translated mesh, a plane
+    scene = rt.Scene(desc)
+    ctx.upload(scene)
+    orc = ob.OracleScene(desc)
+    v, t = desc.meshes[0].arrays()
+    rng = np.random.default_rng(17)
+    axes = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]], np.float32)
+    org, dr = [], []
+    vi = rng.integers(0, len(v), 600)
+    org.append(v[vi]); dr.append(axes[rng.integers(0, 6, 600)])                      # from a vertex, along an axis
+    tri = t[rng.integers(0, len(t), 600)]
+    org.append(v[tri[:, 0]]); dr.append(v[tri[:, 1]] - v[tri[:, 0]])                 # along an edge, un-normalised
+    org.append(((v[tri[:, 0]] + v[tri[:, 1]]) * np.float32(0.5)).astype(np.float32)); dr.append(-axes[rng.integers(0, 6, 600)])
+    o = rng.uniform(-1.5, 1.5, (600, 3)).astype(np.float32)
+    org.append(o); dr.append((v[rng.integers(0, len(v), 600)] - o) * np.float32(3.0))  # exactly through a vertex, length != 1
+    o = rng.uniform(-1.0, 1.0, (8, 3)).astype(np.float32)
+    special = np.array([[0, 0, 0], [np.inf, 0, 0], [np.nan, 0, 1], [0, np.nan, np.nan], [1e-38, 0, 0], [-0.0, -0.0, 1],
+                        [np.inf, -np.inf, 1], [1e30, 1e30, 1e30]], np.float32)
+    org.append(o); dr.append(special)
+    org = np.concatenate(org).astype(np.float32)
+    dr = np.concatenate(dr).astype(np.float32)
+    for t_min, t_max in [(1e-3, np.inf), (0.0, np.inf), (0.0, 0.7)]:
+        want = orc.trace_closest(org, dr, t_min, t_max)
+        wa = orc.trace_any(org, dr, t_min, t_max)
+        for counters in (False, True):
+            got = ctx.trace_closest(org, dr, t_min, t_max, counters=counters)
+            for k in ("obj", "prim", "front_face"):
+                assert np.array_equal(got[k], want[k]), (t_min, t_max, counters, k)
+            for k in ("t", "nx", "ny", "nz"):
+                assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (t_min, t_max, counters, k)
+            ga = ctx.trace_any(org, dr, t_min, t_max, counters=counters)
+            assert np.array_equal(ga["occluded"], wa["occluded"]), (t_min, t_max, counters)
+            if counters:
+                assert np.array_equal(got["n_int"], want["n_int"]) and np.array_equal(got["n_tri"], want["n_tri"])
+    assert (want["obj"] != rt.api.RT_MISS).sum() > 500
+
+
 def test_analytic_surfaces_and_transforms(ctx):
     """scene_primitives (src/main.rs:302-397) + transformed objects (object.rs:32-87)."""
     desc = scenes.primitives_scene()
