@@ -32,13 +32,14 @@ int on_exception(const char* who) noexcept;  // host/mesh.cpp: maps the exceptio
 #define RT_TRACE_ATTR __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU)))
 #define RT_TRACE_ATTR_ANY __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_ANY)))
 #ifndef RT_WAVES_EU_LEAN
-#define RT_WAVES_EU_LEAN 6  // scenes without analytic sphere/triangle objects (device_trace.h, SceneFeatures)
+#define RT_WAVES_EU_LEAN 7  // scenes without analytic sphere/triangle objects (device_trace.h, SceneFeatures); 5 / 6 / 7 waves:
+                            // 54.4 / 54.2 / 53.0 ms per 1080p 64-spp frame (profiles/r02/tuning.md); 7 blocks of 20 KiB LDS fit a CU
 #endif
 #ifndef RT_LEAN_FEAT
 #define RT_LEAN_FEAT 1u     // what the lean kernels still support: rtd::FEAT_TRANSFORM
 #endif
 #ifndef RT_WAVES_EU_LEAN_ANY
-#define RT_WAVES_EU_LEAN_ANY 6
+#define RT_WAVES_EU_LEAN_ANY 7
 #endif
 #define RT_TRACE_ATTR_LEAN __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_LEAN)))
 #define RT_TRACE_ATTR_LEAN_ANY __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_LEAN_ANY)))
@@ -57,8 +58,8 @@ constexpr int RT_STACK_ANY = RT_STACK_ANY_N;  // same for the any-hit kernels
 #ifndef RT_STACK_LEAN_ANY_N
 #define RT_STACK_LEAN_ANY_N 20
 #endif
-constexpr int RT_STACK_LEAN = RT_STACK_LEAN_N;          // lean kernels: 20 KiB per block, 6 blocks per CU (26 KiB still fits 6 but measured 2 ms slower per frame)
-constexpr int RT_STACK_LEAN_ANY = RT_STACK_LEAN_ANY_N;  // lean any-hit kernel: the same (7 waves measured no faster than 6)
+constexpr int RT_STACK_LEAN = RT_STACK_LEAN_N;          // lean kernels: 20 KiB per block, 7 blocks per CU (71 VGPRs, no spills)
+constexpr int RT_STACK_LEAN_ANY = RT_STACK_LEAN_ANY_N;  // lean any-hit kernel: the same
 constexpr int rt_min_i(int a, int b) { return a < b ? a : b; }
 constexpr int RT_STACK_MIN = rt_min_i(rt_min_i(RT_STACK_LEAN, RT_STACK_LEAN_ANY), rt_min_i(RT_STACK_LDS, RT_STACK_ANY));
 constexpr int RT_TRACE_GRID = 2048;  // workgroups of the grid-stride trace kernels (8 per CU)
