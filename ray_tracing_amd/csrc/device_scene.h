@@ -53,11 +53,13 @@ struct DScene {
     int32_t initial_medium;
     uint32_t stack_need;  // deepest traversal stack any mesh of the scene can need
     uint32_t tri_off;     // byte offset of tris from pairs (one allocation, < 4 GiB, 64 B of slack after it)
-    // Top level over OBJECTS (flat): world-space bounds of the first 64 objects, 8 floats each (lower xyz, upper
-    // xyz, 2 unused); bit k of cull_test = object k has bounds worth testing.  A ray that misses object k's bounds
-    // cannot hit object k (rt_upload_scene says why), so the traversal leaves k out of its object loop.
+    // Top level over OBJECTS (flat): world-space bounds of up to 64 groups of 2^cull_shift consecutive objects (one
+    // object per group in scenes of at most 64), 8 floats each (lower xyz, upper xyz, 2 unused); bit g of cull_test =
+    // group g has bounds worth testing.  A ray that misses group g's bounds cannot hit any object of the group
+    // (rt_upload_scene says why), so the traversal leaves them out of its object loop.
     const float* wbox;
     unsigned long long cull_test;
+    uint32_t cull_shift;
 };
 
 // The same records seen through the CONSTANT address space: a load through these with a wave-uniform index

@@ -140,7 +140,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     bool got = false;                                 // a hit has been recorded through io.hit()
     uint32_t hit_tri = 0;
     bool hit_ff = false, obj_hit = false, fresh = false;
-    unsigned long long cand = ~0ull;                  // objects (of the first 64) this ray can hit at all
+    unsigned long long cand = ~0ull;                  // object groups this ray can hit at all
     bool lane_any = MODE == TRACE_ANY;                // TRACE_PATH: kind of this lane's current ray
     bool done_occluded = false;                       // TRACE_PATH: outcome of a finished any-hit ray
     Visits vis = {0, 0};
@@ -199,11 +199,15 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             }
         }
     };
-    // the first object >= from that the ray can hit (objects past the 64th are always candidates)
+    // the first object >= from that the ray can hit: `from` itself when its group is a candidate, else the first
+    // object of the next candidate group (n_objects when there is none)
     auto next_cand = [&](uint32_t from) -> uint32_t {
         if (COUNT == COUNT_REFERENCE) return from;
-        const unsigned long long rem = from < 64u ? cand & (~0ull << from) : 0ull;
-        return rem != 0ull ? (uint32_t)__builtin_ctzll(rem) : max(from, 64u);
+        const uint32_t g = from >> sc.cull_shift;
+        const unsigned long long rem = g < 64u ? cand & (~0ull << g) : 0ull;
+        if (rem == 0ull) return sc.n_objects;
+        const uint32_t g2 = (uint32_t)__builtin_ctzll(rem);
+        return g2 == g ? from : g2 << sc.cull_shift;
     };
 
     for (;;) {

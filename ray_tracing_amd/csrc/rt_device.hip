@@ -433,52 +433,61 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) try {
         o.medium_inside = f.medium_inside;
         o.medium_outside = f.medium_outside;
     }
-    // ---- top level over objects (DScene::wbox): world-space bounds of every mesh among the first 64 objects.
-    // Without a transform, and with an internal root, the object loop's exact root-box test (device_trace.h)
-    // already does this at the same price: no entry.  Otherwise the box is the hull of the 8
-    // root-box corners taken to world space in f64, widened by 1e-4 of the scene scale: a hit the reference
-    // finds lies within a few f32 roundings (1e-7 relative) of a triangle, all triangles lie inside the root
-    // box, so its ray passes the widened box with a margin three orders above every rounding on the way.
+    // ---- top level over objects (DScene::wbox): world-space bounds of up to 64 GROUPS of 2^cull_shift consecutive
+    // objects (one object per group while the scene has at most 64).  A group has an entry when every object in it
+    // is a mesh; its box is the union of its objects' boxes.  With one object per group a mesh without a transform
+    // and with an internal root gets no entry: the object loop's exact root-box test (device_trace.h) already does
+    // that at the same price.  An object's box is the hull of the 8 root-box corners taken to world space in
+    // f64, widened by 1e-4 of the scene scale: a hit the reference finds lies within a few f32 roundings (1e-7
+    // relative) of a triangle, all triangles lie inside the root box, so its ray passes the widened box with a
+    // margin three orders above every rounding on the way.
+    uint32_t cull_shift = 0;
+    while (((uint64_t)64 << cull_shift) < s->n_objects) ++cull_shift;
+    auto world_box = [&](const DObject& o, double* lo, double* hi) -> bool {
+        double m[9], inv[9];  // forward matrix = inverse of the stored inverse; identity without a transform
+        for (int a = 0; a < 9; ++a) m[a] = o.has_transform ? (double)o.inv_m[a] : (a % 4 == 0 ? 1.0 : 0.0);
+        const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+                           m[2] * (m[3] * m[7] - m[4] * m[6]);
+        if (!(std::fabs(det) > 1e-30)) return false;
+        inv[0] = (m[4] * m[8] - m[5] * m[7]) / det, inv[1] = (m[2] * m[7] - m[1] * m[8]) / det, inv[2] = (m[1] * m[5] - m[2] * m[4]) / det;
+        inv[3] = (m[5] * m[6] - m[3] * m[8]) / det, inv[4] = (m[0] * m[8] - m[2] * m[6]) / det, inv[5] = (m[2] * m[3] - m[0] * m[5]) / det;
+        inv[6] = (m[3] * m[7] - m[4] * m[6]) / det, inv[7] = (m[1] * m[6] - m[0] * m[7]) / det, inv[8] = (m[0] * m[4] - m[1] * m[3]) / det;
+        for (int a = 0; a < 3; ++a) lo[a] = 1e300, hi[a] = -1e300;
+        for (int c = 0; c < 8; ++c) {
+            double x[3];
+            for (int a = 0; a < 3; ++a)
+                x[a] = (double)((c >> a) & 1 ? o.surf[3 + a] : o.surf[a]) - (o.has_transform ? (double)o.inv_t[a] : 0.0);
+            for (int a = 0; a < 3; ++a) {
+                const double w = inv[3 * a] * x[0] + inv[3 * a + 1] * x[1] + inv[3 * a + 2] * x[2];
+                lo[a] = std::min(lo[a], w), hi[a] = std::max(hi[a], w);
+            }
+        }
+        double scale = 0.0;
+        for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::max(std::fabs(lo[a]), std::fabs(hi[a])), hi[a] - lo[a]));
+        const double pad = 1e-4 * scale + 1e-30;
+        for (int a = 0; a < 3; ++a) lo[a] -= pad, hi[a] += pad;
+        return std::isfinite(lo[0] + lo[1] + lo[2] + hi[0] + hi[1] + hi[2]);
+    };
     std::vector<float> wbox(8 * 64, 0.0f);
     unsigned long long cull_test = 0;
-    for (uint32_t i = 0; i < s->n_objects && i < 64u; ++i) {
-        const DObject& o = objs[i];
-        if (o.kind != RT_SURF_MESH) continue;
-        double lo[3], hi[3];
+    for (uint32_t g = 0; g < 64u && ((uint64_t)g << cull_shift) < s->n_objects; ++g) {
+        const uint32_t first = g << cull_shift, last = (uint32_t)std::min<uint64_t>((uint64_t)first + (1u << cull_shift), s->n_objects);
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         bool ok = true;
-        if (!o.has_transform && (o.root_ref & rtd::LEAF_BIT) == 0u) {
-            continue;  // the object loop's own root-box test is this very test, and costs the same
-        } else {
-            double m[9], inv[9];  // forward matrix = inverse of the stored inverse; identity without a transform
-            for (int a = 0; a < 9; ++a) m[a] = o.has_transform ? (double)o.inv_m[a] : (a % 4 == 0 ? 1.0 : 0.0);
-            const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
-                               m[2] * (m[3] * m[7] - m[4] * m[6]);
-            if (!(std::fabs(det) > 1e-30)) continue;
-            inv[0] = (m[4] * m[8] - m[5] * m[7]) / det, inv[1] = (m[2] * m[7] - m[1] * m[8]) / det, inv[2] = (m[1] * m[5] - m[2] * m[4]) / det;
-            inv[3] = (m[5] * m[6] - m[3] * m[8]) / det, inv[4] = (m[0] * m[8] - m[2] * m[6]) / det, inv[5] = (m[2] * m[3] - m[0] * m[5]) / det;
-            inv[6] = (m[3] * m[7] - m[4] * m[6]) / det, inv[7] = (m[1] * m[6] - m[0] * m[7]) / det, inv[8] = (m[0] * m[4] - m[1] * m[3]) / det;
-            for (int a = 0; a < 3; ++a) lo[a] = 1e300, hi[a] = -1e300;
-            for (int c = 0; c < 8; ++c) {
-                double x[3];
-                for (int a = 0; a < 3; ++a)
-                    x[a] = (double)((c >> a) & 1 ? o.surf[3 + a] : o.surf[a]) - (o.has_transform ? (double)o.inv_t[a] : 0.0);
-                for (int a = 0; a < 3; ++a) {
-                    const double w = inv[3 * a] * x[0] + inv[3 * a + 1] * x[1] + inv[3 * a + 2] * x[2];
-                    lo[a] = std::min(lo[a], w), hi[a] = std::max(hi[a], w);
-                }
-            }
-            double scale = 0.0;
-            for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::max(std::fabs(lo[a]), std::fabs(hi[a])), hi[a] - lo[a]));
-            const double pad = 1e-4 * scale + 1e-30;
-            for (int a = 0; a < 3; ++a) lo[a] -= pad, hi[a] += pad;
+        for (uint32_t i = first; i < last && ok; ++i) {
+            const DObject& o = objs[i];
+            double l[3], h[3];
+            ok = o.kind == RT_SURF_MESH && !(cull_shift == 0 && !o.has_transform && (o.root_ref & rtd::LEAF_BIT) == 0u) &&
+                 world_box(o, l, h);
+            for (int a = 0; a < 3 && ok; ++a) lo[a] = std::min(lo[a], l[a]), hi[a] = std::max(hi[a], h[a]);
         }
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < 3 && ok; ++a) {
             const float l = (float)lo[a], h = (float)hi[a];
             if (!std::isfinite(l) || !std::isfinite(h) || !(l <= h)) ok = false;
-            wbox[8 * i + a] = (double)l <= lo[a] ? l : std::nextafterf(l, -INFINITY);
-            wbox[8 * i + 3 + a] = (double)h >= hi[a] ? h : std::nextafterf(h, INFINITY);
+            wbox[8 * g + a] = (double)l <= lo[a] ? l : std::nextafterf(l, -INFINITY);
+            wbox[8 * g + 3 + a] = (double)h >= hi[a] ? h : std::nextafterf(h, INFINITY);
         }
-        if (ok) cull_test |= 1ull << i;
+        if (ok) cull_test |= 1ull << g;
     }
     // ---- materials, lights, media: records the kernels switch on and loop over.  An unknown kind would fall into
     // an else branch silently; a checkered medium with a cell size <= 0 or NaN never advances its DDA
@@ -558,6 +567,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) try {
     d.stack_need = stack_need;
     d.wbox = (const float*)ctx->wbox.p;
     d.cull_test = cull_test;
+    d.cull_shift = cull_shift;
     ctx->overflow_levels = stack_need > (uint32_t)RT_STACK_MIN ? stack_need - RT_STACK_MIN : 0;
     ctx->features = features;
     ctx->has_scene = true;

@@ -36,21 +36,23 @@ def _rotation(rng):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float32)
 
 
-def test_top_level_cull_changes_nothing(ctx):
+@pytest.mark.parametrize("n_obj", [40, 70, 300])
+def test_top_level_cull_changes_nothing(ctx, n_obj):
     """The flat top level over objects (DScene::wbox, device_trace.h) leaves objects whose world bounds a
-    ray misses out of Engine::hit's loop (path_integrator.rs:88-104).  70 objects -- more than the 64 the
-    candidate mask covers -- with rotated, scaled and translated meshes, a leaf-root mesh, planes and a
-    sphere in between; rays through pixel centres, random rays and rays aimed at the corners of every
-    object's world bounds.  The culling kernels (no counters) must give the oracle's bits; so must the
-    counting kernels, which do not cull."""
+    ray misses out of Engine::hit's loop (path_integrator.rs:88-104).  40 objects: one bit of the candidate
+    mask each; 70 / 300: more than the mask's 64 bits, so a bit stands for a group of 2 / 8 consecutive objects
+    and a group with a plane or a sphere in it is always a candidate.  Rotated, scaled and translated meshes,
+    a leaf-root mesh, planes and a sphere in between; rays through pixel centres, random rays and rays aimed
+    at the corners of every object's world bounds.  The culling kernels (no counters) must give the oracle's
+    bits; so must the counting kernels (reference visits: no cull; fetches: cull)."""
     rng = np.random.default_rng(11)
     desc = scenes.SceneDescription()
     mats = [desc.diffuse((0.8, 0.3, 0.2)), desc.dielectric(1.5), desc.diffuse((0.2, 0.3, 0.8))]
     small, big, single = scenes.tetrahedron_mesh(1), scenes.tetrahedron_mesh(3), scenes.tetrahedron_mesh(0)
     corners = []
-    for i in range(70):
-        pos = np.array([(i % 10 - 4.5) * 1.1, (i // 10 - 3.0) * 1.1, 0.3 * np.sin(i)], np.float32)
-        if i in (5, 66):
+    for i in range(n_obj):
+        pos = np.array([(i % 10 - 4.5) * 1.1, (i // 10 % 7 - 3.0) * 1.1, 0.3 * np.sin(i) + 1.5 * (i // 70)], np.float32)
+        if i in (5, 66, 131):
             desc.add_plane((0.0, 0.0, -1.0 - 0.01 * i), (0.0, 0.0, 1.0), mats[0])
             continue
         if i == 17:
@@ -84,13 +86,21 @@ def test_top_level_cull_changes_nothing(ctx):
     dr = (dr / np.linalg.norm(dr, axis=1, keepdims=True)).astype(np.float32)
 
     o = orc.trace_closest(org, dr)
-    assert len(np.unique(o["obj"])) >= 15 and ((o["obj"] >= 64) & (o["obj"] != rt.api.RT_MISS)).any()
-    for counters in (False, True):
+    hit_objs = np.unique(o["obj"][o["obj"] != rt.api.RT_MISS])
+    assert len(hit_objs) >= 15 and hit_objs.max() >= min(n_obj, 65) - 5
+    for counters, mode in ((False, None), (True, rt.api.COUNT_REFERENCE), (True, rt.api.COUNT_FETCHES)):
+        if mode is not None:
+            ctx.set_visit_count_mode(mode)
         g = ctx.trace_closest(org, dr, counters=counters)
         for k in ("obj", "prim", "front_face"):
-            assert np.array_equal(g[k], o[k]), (counters, k)
+            assert np.array_equal(g[k], o[k]), (counters, mode, k)
         for k in ("t", "nx", "ny", "nz"):
-            assert np.array_equal(g[k].view(np.uint32), o[k].view(np.uint32)), (counters, k)
+            assert np.array_equal(g[k].view(np.uint32), o[k].view(np.uint32)), (counters, mode, k)
+        if mode == rt.api.COUNT_REFERENCE:
+            assert np.array_equal(g["n_int"], o["n_int"]) and np.array_equal(g["n_tri"], o["n_tri"])
+        if mode == rt.api.COUNT_FETCHES:  # the cull leaves whole objects out: fewer fetches, never more
+            assert (g["n_int"] <= o["n_int"]).all() and g["n_int"].sum() < o["n_int"].sum()
+    ctx.set_visit_count_mode(rt.api.COUNT_REFERENCE)
     p = (org + dr * np.minimum(o["t"], 20.0)[:, None] * np.float32(0.999)).astype(np.float32)
     dl = rng.normal(size=p.shape).astype(np.float32)
     dl = (dl / np.linalg.norm(dl, axis=1, keepdims=True)).astype(np.float32)
