@@ -342,7 +342,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, desc, scene, width, height)
-        print(json.dumps(out))
+        os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
@@ -435,5 +435,13 @@ def cpu_baseline(args, desc, scene, width, height):
                           "seconds": round(secs_all, 1)}}
 
 
+_JSON_FD = 1
+
+
 if __name__ == "__main__":
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner at its first
+    # init when NCCL_DEBUG is set on the box): everything but the result line goes to stderr.
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     main()
