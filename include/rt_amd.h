@@ -339,6 +339,7 @@ typedef struct rt_comm rt_comm;
 int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
 /* ncclCommInitRank on ctx's device; collective over all world_size ranks. */
 int rt_comm_create(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], int world_size, int rank, rt_comm** out);
+/* Waits for ctx's stream, then ncclCommDestroy.  Call it BEFORE rt_destroy(ctx): the communicator keeps the pointer. */
 void rt_comm_destroy(rt_comm* comm);
 /* Sum of the ranks' rgb_sum[height][width][3] (DEVICE memory, in place) onto rank `root` (ncclReduce), or onto
    every rank when root < 0 (ncclAllReduce).  Enqueued on the context's stream, i.e. behind the rt_render call

@@ -42,7 +42,8 @@ Rccl* rccl() {
         for (const char* n : names)
             if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
         if (!r.handle) {
-            r.error = std::string("librccl.so.1 not found (") + (dlerror() ? dlerror() : "?") + ")";
+            const char* why = dlerror();  // one call: dlerror() clears the message it returns
+            r.error = std::string("librccl.so.1 not found (") + (why ? why : "?") + ")";
             return;
         }
         auto sym = [&](const char* name) -> void* {

@@ -43,9 +43,19 @@ int rt_trace_grid(size_t n) {
 
 int rt_ctx_ensure_readback(rt_ctx* ctx) {
     if (ctx->rb_host) return RT_OK;
-    RT_HIP(hipHostMalloc((void**)&ctx->rb_host, RT_READBACK_RING * 4 * sizeof(uint32_t), hipHostMallocDefault));
-    memset(ctx->rb_host, 0, RT_READBACK_RING * 4 * sizeof(uint32_t));
-    for (size_t i = 0; i < RT_READBACK_RING; ++i) RT_HIP(hipEventCreateWithFlags(&ctx->rb_ev[i], hipEventDisableTiming));
+    uint32_t* host = nullptr;
+    RT_HIP(hipHostMalloc((void**)&host, RT_READBACK_RING * 4 * sizeof(uint32_t), hipHostMallocDefault));
+    memset(host, 0, RT_READBACK_RING * 4 * sizeof(uint32_t));
+    for (size_t i = 0; i < RT_READBACK_RING; ++i) {
+        if (ctx->rb_ev[i]) continue;  // kept from an attempt that failed further on
+        const hipError_t e = hipEventCreateWithFlags(&ctx->rb_ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) {  // all or nothing: rb_host set means every event exists
+            ctx->rb_ev[i] = nullptr;
+            (void)hipHostFree(host);
+            RT_HIP(e);
+        }
+    }
+    ctx->rb_host = host;
     return RT_OK;
 }
 
