@@ -346,6 +346,15 @@ void rt_comm_destroy(rt_comm* comm);
    that filled rgb_sum; returns when the result is complete.  24.9 MB at 1080p, 99.5 MB at 4K. */
 int rt_reduce_accum(rt_comm* comm, float* rgb_sum, uint32_t width, uint32_t height, int root);
 
+/* Engine::ray_colour (path_integrator.rs:138-276, the crate's public per-ray entry) in batch form: rgb_sum[3k..] =
+   sum over the samples [spp_first, spp_first + spp_count) of ray_colour(ray k, depth).  Ray k is taken as it is (the
+   reference's callers pass Camera::ray's normalised direction); the random numbers of (ray k, sample s) are those
+   of pixel index k and sample s from bounce 1 on -- rendering the rays Camera::ray produces
+   for the jittered pixel positions gives rt_render's image.  Same pipeline, flags and statistics as rt_render;
+   rays and rgb_sum (3 n floats) may be host or device memory. */
+int rt_ray_colour(rt_ctx* ctx, const rt_rays* rays, size_t n, uint32_t spp_first, uint32_t spp_count, uint32_t depth,
+                  uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats);
+
 /* Upper bound on camera paths kept in flight by rt_render (default: sized from free HBM). */
 int rt_set_max_paths_in_flight(rt_ctx* ctx, uint64_t max_paths);
 

@@ -311,6 +311,33 @@ int orc_render_pixels(const orc_scene* s, uint32_t width, uint32_t height, uint3
     return 0;
 }
 
+// Engine::ray_colour (path_integrator.rs:138-276) for a list of rays: out[k*3..] = sum over the samples of
+// ray_colour(ray k, depth) with the random numbers of (pixel index k, sample s); the ray is taken as given.
+int orc_ray_colour(const orc_scene* s, const float* ox, const float* oy, const float* oz, const float* dx,
+                   const float* dy, const float* dz, size_t n, uint32_t spp_first, uint32_t spp_count, uint32_t depth,
+                   uint64_t seed, float* out, orc_stats* stats) {
+    RayCounters rc;
+    g_visits = VisitCounters();
+    for (size_t k = 0; k < n; ++k) {
+        Vec3D colour = ZERO;
+        for (uint32_t sm = spp_first; sm < spp_first + spp_count; ++sm) {
+            Rng rng(seed, (uint32_t)k, sm);
+            colour += s->engine.ray_colour(Ray{Vec3D{ox[k], oy[k], oz[k]}, Vec3D{dx[k], dy[k], dz[k]}}, depth, rng, &rc);
+        }
+        out[3 * k] = colour.x; out[3 * k + 1] = colour.y; out[3 * k + 2] = colour.z;
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->rays_closest = rc.closest;
+        stats->rays_shadow = rc.shadow;
+        stats->iterations = rc.iterations;
+        stats->nodes_visited = g_visits.n_int;
+        stats->tris_tested = g_visits.n_tri;
+        stats->threads = 1;
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------- unit probes for the golden tests
 // AxisAlignedBoundingBox::new + hit (primitives.rs:257-261, :304-321). Returns 1 and *t for Some(t).
 int orc_aabb_hit(const float a[3], const float b[3], const float o[3], const float d[3], float t_min, float t_max,

@@ -124,7 +124,7 @@ class Stats(C.Structure):
 EXPORTS = ["rt_mesh_create", "rt_mesh_read_stl", "rt_mesh_loop_subdivide", "rt_mesh_apply_transform",
            "rt_mesh_volume_centroid", "rt_mesh_counts", "rt_mesh_copy_out", "rt_mesh_destroy", "rt_scene_build",
            "rt_scene_view", "rt_scene_destroy", "rt_tonemap_u8", "rt_write_ppm", "rt_create", "rt_destroy",
-           "rt_upload_scene", "rt_initial_medium", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render",
+           "rt_upload_scene", "rt_initial_medium", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render", "rt_ray_colour",
            "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy", "rt_reduce_accum",
            "rt_set_max_paths_in_flight", "rt_set_visit_count_mode", "rt_last_kernel_ms", "rt_stream", "rt_last_error", "rt_version"]
 
@@ -169,6 +169,8 @@ lib.rt_trace_any.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.c_float,
                              C.c_void_p]
 lib.rt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                           C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+lib.rt_ray_colour.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                              C.c_uint32, C.c_void_p, C.POINTER(Stats)]
 lib.rt_comm_unique_id.argtypes = [C.c_void_p]
 lib.rt_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
 lib.rt_comm_destroy.argtypes = [C.c_void_p]
@@ -469,6 +471,19 @@ class Context:
             out = np.empty((height, width, 3), np.float32)
         _check(lib.rt_render(self.handle, width, height, spp_first, spp, depth, seed, flags, _ptr(out),
                              C.byref(stats)))
+        return out, stats
+
+    def ray_colour(self, origins, directions, spp, depth, seed=0, spp_first=0, flags=0):
+        """Engine::ray_colour for a batch of rays: (n, 3) sums over the samples, and the statistics of the run."""
+        o = _f32(origins).reshape(-1, 3)
+        d = _f32(directions).reshape(-1, 3)
+        n = len(o)
+        cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(d[:, k]) for k in range(3)]
+        rays = Rays(*[c.ctypes.data for c in cols])
+        out = np.zeros((n, 3), np.float32)
+        stats = Stats()
+        _check(lib.rt_ray_colour(self.handle, C.byref(rays), n, spp_first, spp, depth, seed, flags, _ptr(out),
+                                 C.byref(stats)))
         return out, stats
 
     def close(self):

@@ -98,6 +98,9 @@ struct rt_ctx {
 constexpr size_t RT_READBACK_RING = 8;  // the host is at most two bounces ahead of the counts it has read
 int rt_ctx_ensure_overflow(rt_ctx* ctx, size_t lanes);
 int rt_ctx_ensure_readback(rt_ctx* ctx);
+// rt_render.hip: the renderer behind rt_render (user_rays null) and rt_ray_colour (device pointers to `width` rays)
+int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* user_rays, uint32_t spp_first,
+                   uint32_t spp_count, uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats);
 
 #ifndef RT_LEAN_OVERFLOW
 #define RT_LEAN_OVERFLOW true  // false: no overflow path in the lean kernels (-1 ms), scenes deeper than the LDS stack take the full ones

@@ -707,6 +707,32 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
     return rth::on_exception("rt_trace_closest");
 }
 
+int rt_ray_colour(rt_ctx* ctx, const rt_rays* rays, size_t n, uint32_t spp_first, uint32_t spp_count, uint32_t depth,
+                  uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats) try {
+    int rc = check_ctx(ctx, true);
+    if (rc != RT_OK) return rc;
+    if (rays_null(rays) || !rgb_sum) {
+        rth::set_error("rt_ray_colour: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (n == 0) return RT_OK;
+    if (n > 0x7FFFFFFFull) {
+        rth::set_error("rt_ray_colour: batch larger than 2^31 - 1 rays");
+        return RT_ERR_LIMIT;
+    }
+    Stager sg{ctx};
+    rt_rays dr;
+    const size_t fb = n * sizeof(float);
+    if ((rc = sg.in(rays->ox, fb, (const void**)&dr.ox)) || (rc = sg.in(rays->oy, fb, (const void**)&dr.oy)) ||
+        (rc = sg.in(rays->oz, fb, (const void**)&dr.oz)) || (rc = sg.in(rays->dx, fb, (const void**)&dr.dx)) ||
+        (rc = sg.in(rays->dy, fb, (const void**)&dr.dy)) || (rc = sg.in(rays->dz, fb, (const void**)&dr.dz)))
+        return rc;
+    // the renderer with the caller's rays in the place of the camera's: "pixel" k is ray k, one row of n pixels
+    return rt_render_impl(ctx, (uint32_t)n, 1u, &dr, spp_first, spp_count, depth, seed, flags, rgb_sum, stats);
+} catch (...) {
+    return rth::on_exception("rt_ray_colour");
+}
+
 int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float t_max, uint8_t* occluded,
                  uint32_t* n_int, uint32_t* n_tri) try {
     int rc = check_ctx(ctx, true);

@@ -99,7 +99,7 @@ RT_DEV float pack_medium(int medium, bool prev_specular) {
 }
 
 // ---------------------------------------------------------------- generate
-__global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, RenderParams rp, uint32_t n_paths) {
+__global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, RenderParams rp, uint32_t n_paths, rt_rays ur) {
     uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (slot >= n_paths) return;
     if (slot == 0) {  // bounce 0: every path is alive, no shadow rays pending
@@ -108,14 +108,20 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
     }
     uint32_t pixel, s_local;
     slot_pixel(rp, slot, &pixel, &s_local);
-    uint32_t i = pixel % rp.width, j = pixel / rp.width;
-    Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + s_local, 0u, 0u};
-    // path_integrator.rs:303-305
-    float u = ((float)i + rng.f32()) / (float)(rp.width - 1);
-    float v = ((float)j + rng.f32()) / (float)(rp.height - 1);
-    V3 origin = ld3(sc.camera.origin);
-    V3 dir = ld3(sc.camera.lower_left_corner) + u * ld3(sc.camera.horizontal) + v * ld3(sc.camera.vertical) - origin;
-    dir = normalise(dir);  // camera.rs:60-63
+    V3 origin, dir;
+    if (ur.ox) {  // uniform: rt_ray_colour -- "pixel" k is the caller's ray k, taken as it is (no jitter draws)
+        origin = v3(ur.ox[pixel], ur.oy[pixel], ur.oz[pixel]);
+        dir = v3(ur.dx[pixel], ur.dy[pixel], ur.dz[pixel]);
+    } else {
+        uint32_t i = pixel % rp.width, j = pixel / rp.width;
+        Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + s_local, 0u, 0u};
+        // path_integrator.rs:303-305
+        float u = ((float)i + rng.f32()) / (float)(rp.width - 1);
+        float v = ((float)j + rng.f32()) / (float)(rp.height - 1);
+        origin = ld3(sc.camera.origin);
+        dir = ld3(sc.camera.lower_left_corner) + u * ld3(sc.camera.horizontal) + v * ld3(sc.camera.vertical) - origin;
+        dir = normalise(dir);  // camera.rs:60-63
+    }
     // :139-148: beta = 1, radiance = 0, prev_pdf = 1, prev_specular = true, current medium = initial
     if (!rp.implicit_first) {
         pa.ray_o[slot] = make_float4(origin.x, origin.y, origin.z, pack_medium(sc.initial_medium, true));
@@ -880,8 +886,10 @@ bool is_device_ptr(const void* p) {
 
 }  // namespace
 
-extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp_first, uint32_t spp_count,
-                         uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats) try {
+// The wavefront renderer behind rt_render (user_rays == nullptr: camera paths of a width x height image) and
+// rt_ray_colour (user_rays: device pointers to `width` caller rays, height 1; "pixel" k is ray k).
+int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* user_rays, uint32_t spp_first,
+                   uint32_t spp_count, uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats) {
     if (!ctx || !rgb_sum) {
         rth::set_error("rt_render: null argument");
         return RT_ERR_INVALID;
@@ -890,10 +898,12 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         rth::set_error("rt_render: no scene uploaded (call rt_upload_scene first)");
         return RT_ERR_STATE;
     }
-    if (width < 2 || height < 2) {  // the reference divides by (w-1), (h-1) (:303-304)
+    if (!user_rays && (width < 2 || height < 2)) {  // the reference divides by (w-1), (h-1) (:303-304)
         rth::set_error("rt_render: width and height must be >= 2");
         return RT_ERR_INVALID;
     }
+    const rt_rays no_rays = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const rt_rays gen_rays = user_rays ? *user_rays : no_rays;
     const uint64_t npix64 = (uint64_t)width * height;
     if (npix64 > 0x7FFFFFFFull) {
         rth::set_error("rt_render: image too large");
@@ -1148,13 +1158,13 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
         rp.s_count = s_count;
         // first-bounce state implicit unless the tail kernel takes the batch from its first bounce (it reads
         // every path's state from memory)
-        const bool implicit = depth > 0 && !(use_tail && n_paths <= tail_paths) && getenv("RT_NO_IMPLICIT") == nullptr;
+        const bool implicit = !user_rays && depth > 0 && !(use_tail && n_paths <= tail_paths) && getenv("RT_NO_IMPLICIT") == nullptr;
         rp.implicit_first = implicit ? 1u : 0u;
         rp.identity_queue = 1u;
         rp.bounce = 0u;
         RT_HIP(hipMemsetAsync(pa.work, 0, 2 * rtd::WORK_U32 * 4, stream));
         if ((rc = t_begin(0)) != RT_OK) return rc;
-        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, reg[0], rp, n_paths);
+        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, reg[0], rp, n_paths, gen_rays);
         if ((rc = t_end(0)) != RT_OK) return rc;
         st.paths += n_paths;
         st.batches += 1;
@@ -1343,6 +1353,11 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     st.ms_compact = stage_ms[4];
     if (stats) *stats = st;
     return RT_OK;
+}
+
+extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp_first, uint32_t spp_count,
+                         uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats) try {
+    return rt_render_impl(ctx, width, height, nullptr, spp_first, spp_count, depth, seed, flags, rgb_sum, stats);
 } catch (...) {
     return rth::on_exception("rt_render");
 }

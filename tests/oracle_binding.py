@@ -51,6 +51,8 @@ lib.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_u
                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(OrcStats)]
 
 
+lib.orc_ray_colour.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                               C.c_void_p, C.c_void_p]
 lib.orc_render_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                   C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.POINTER(OrcStats)]
 
@@ -61,6 +63,11 @@ def f3(v):
 
 def f9(m):
     return (C.c_float * 9)(*[float(np.float32(x)) for x in np.asarray(m).ravel()])
+
+
+def rng_f32(seed, pixel, sample, bounce, dim):
+    """Draw `dim` of (pixel, sample, bounce) as an f32 in [0, 1) (oracle/rng.h)."""
+    return lib.orc_rng_f32(seed, pixel, sample, bounce, dim)
 
 
 class OracleScene:
@@ -136,6 +143,24 @@ class OracleScene:
         st = OrcStats()
         lib.orc_render_pixels(self.handle, width, height, spp_first, spp, depth, seed, px.ctypes.data, len(px), threads,
                               out.ctypes.data, C.byref(st))
+        return out, st
+
+    def camera_rays(self, u, v):
+        """Camera::ray(u, v) (camera.rs:60-63) for arrays of image-plane positions."""
+        u = np.ascontiguousarray(u, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        cols = [np.empty(len(u), np.float32) for _ in range(6)]
+        lib.orc_camera_rays(C.c_void_p(self.handle), C.c_void_p(u.ctypes.data), C.c_void_p(v.ctypes.data),
+                            C.c_size_t(len(u)), *[C.c_void_p(c.ctypes.data) for c in cols])
+        return np.stack(cols[:3], 1), np.stack(cols[3:], 1)
+
+    def ray_colour(self, origins, directions, spp, depth, seed=0, spp_first=0):
+        cols = self._cols(origins, directions)
+        n = len(cols[0])
+        out = np.zeros((n, 3), np.float32)
+        st = OrcStats()
+        lib.orc_ray_colour(self.handle, *[c.ctypes.data for c in cols], n, spp_first, spp, depth, seed, out.ctypes.data,
+                           C.byref(st))
         return out, st
 
     def __del__(self):
