@@ -210,3 +210,79 @@ def test_errors_are_reported_not_thrown(ctx):
     d.lights[0].kind = 7
     with pytest.raises(rt.RtError):
         ctx.upload(rt.Scene(d))
+
+
+def test_flat_axis_aligned_meshes(ctx):
+    """AxisAlignedBoundingBox::hit returns None when t_max <= t_min (primitives.rs:316): the boxes of a flat,
+    axis-aligned mesh have no thickness, a ray crossing the plane gets t_min == t_max there, and the reference never
+    reaches the triangles -- except in a mesh whose ROOT is a leaf (the root is never box-tested, bvh.rs:252).  The
+    device must reproduce both: a flat grid of 2 x 8 x 8 triangles (invisible from the front, hit only along rays
+    inside its plane's slab arithmetic allows), flat one- and two-triangle meshes (visible), each also under a
+    rotation + scaling (the object-space boxes stay flat) -- where the top-level world bounds and the root-box skip
+    must not lose what the reference hits.  All three count modes, closest and any-hit."""
+    rng = np.random.default_rng(3)
+    g = 8
+    xs = np.linspace(-1.0, 1.0, g + 1, dtype=np.float32)
+    verts = np.array([(x, y, 0.0) for y in xs for x in xs], np.float32)
+    tris = []
+    for j in range(g):
+        for i in range(g):
+            a, b, c, d = j * (g + 1) + i, j * (g + 1) + i + 1, (j + 1) * (g + 1) + i, (j + 1) * (g + 1) + i + 1
+            tris += [(a, b, d), (a, d, c)]
+    grid = rt.Mesh.from_arrays(verts, np.array(tris, np.uint32))
+    one = rt.Mesh.from_arrays(np.array([(-1, -1, 0), (1, -1, 0), (0, 1, 0)], np.float32), np.array([(0, 1, 2)], np.uint32))
+    two = rt.Mesh.from_arrays(np.array([(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], np.float32),
+                              np.array([(0, 1, 2), (0, 2, 3)], np.uint32))
+    desc = scenes.SceneDescription()
+    mat = desc.diffuse((0.8, 0.8, 0.8))
+    rot = np.array([[0.36, 0.48, -0.8], [-0.8, 0.6, 0.0], [0.48, 0.64, 0.6]], np.float32)
+    places = []
+    for k, mesh in enumerate((grid, one, two)):
+        desc.add_mesh(mesh, mat, transform=(np.eye(3, dtype=np.float32), (3.0 * k - 3.0, 0.0, 0.0)))
+        desc.add_mesh(mesh, mat, transform=((rot * np.float32(0.7 + 0.3 * k)).astype(np.float32), (3.0 * k - 3.0, 4.0, 0.5)))
+        places += [np.array([3.0 * k - 3.0, 0.0, 0.0], np.float32), np.array([3.0 * k - 3.0, 4.0, 0.5], np.float32)]
+    desc.point_light((0.0, 0.0, 30.0), (500.0, 500.0, 500.0))
+    desc.set_camera((0.0, -4.0, 12.0), (0.0, 0.45, -1.0), scenes.ASPECT_RATIO)
+    scene = rt.Scene(desc)
+    ctx.upload(scene)
+    orc = ob.OracleScene(desc)
+    # rays at every mesh: from above, from below, skew, and a few lying exactly in the untransformed meshes' plane
+    org, dr = [], []
+    for p in places:
+        for _ in range(400):
+            tgt = p + rng.uniform(-1.0, 1.0, 3).astype(np.float32) * np.array([1.0, 1.0, 0.05], np.float32)
+            o = p + rng.normal(size=3).astype(np.float32) * np.float32(3.0)
+            org.append(o)
+            dr.append(tgt - o)
+        for _ in range(50):
+            o = p + np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.choice([-4.0, 4.0])], np.float32)
+            org.append(o)
+            dr.append(np.array([0.0, 0.0, -np.sign(o[2] - p[2])], np.float32))
+        for _ in range(50):
+            o = p + np.array([-5.0, rng.uniform(-1, 1), 0.0], np.float32)
+            org.append(o)
+            dr.append(np.array([1.0, rng.uniform(-0.2, 0.2), 0.0], np.float32))
+    o2, d2 = scenes.pixel_center_rays(scene.flat.camera, 96, 54)
+    org = np.concatenate([np.array(org, np.float32), o2]).astype(np.float32)
+    dr = np.concatenate([np.array(dr, np.float32), d2]).astype(np.float32)
+    dr = (dr / np.linalg.norm(dr, axis=1, keepdims=True)).astype(np.float32)
+    o = orc.trace_closest(org, dr)
+    hit_obj = o["obj"][o["obj"] != rt.api.RT_MISS]
+    assert set(np.unique(hit_obj)) >= {2, 3, 4, 5}      # the leaf-root meshes are seen, plain and transformed
+    assert (hit_obj <= 1).sum() < 0.2 * ((hit_obj >= 2).sum())  # the grid is (all but) invisible
+    for counters, mode in ((False, None), (True, rt.api.COUNT_REFERENCE), (True, rt.api.COUNT_FETCHES)):
+        if mode is not None:
+            ctx.set_visit_count_mode(mode)
+        gq = ctx.trace_closest(org, dr, counters=counters)
+        for k in ("obj", "prim", "front_face"):
+            assert np.array_equal(gq[k], o[k]), (counters, mode, k)
+        for k in ("t", "nx", "ny", "nz"):
+            assert np.array_equal(gq[k].view(np.uint32), o[k].view(np.uint32)), (counters, mode, k)
+        if mode == rt.api.COUNT_REFERENCE:
+            assert np.array_equal(gq["n_int"], o["n_int"]) and np.array_equal(gq["n_tri"], o["n_tri"])
+        assert np.array_equal(ctx.trace_any(org, dr, counters=counters)["occluded"], orc.trace_any(org, dr)["occluded"])
+    ctx.set_visit_count_mode(rt.api.COUNT_REFERENCE)
+    img, st = ctx.render(96, 54, 2, 6, 4)
+    ref, ost = orc.render(96, 54, 2, 6, 4)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert (st.rays_closest, st.rays_shadow) == (ost.rays_closest, ost.rays_shadow)
