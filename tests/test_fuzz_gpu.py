@@ -4,6 +4,8 @@ Spot, Area), homogeneous and checkered media behind medium interfaces -- drawn f
 rt_render and through the oracle's Engine::render: radiance sums bit-identical, ray counts and visit counters
 equal (tests/test_render_gpu.py::_check, which also runs the non-counting, fetch-counting and no-tail variants).
 The fixed scenes of the other tests are the reference's own; these cover the combinations nobody wrote down."""
+import os
+
 import numpy as np
 import pytest
 
@@ -82,7 +84,7 @@ def random_scene(seed):
     return s
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_SEEDS", "64"))))  # RT_FUZZ_SEEDS=1000: a longer run by hand
 def test_random_scene_matches_the_oracle(ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     depth = int(rng.choice([1, 2, 5, 8, 16]))
