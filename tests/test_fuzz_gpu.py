@@ -90,3 +90,12 @@ def test_random_scene_matches_the_oracle(ctx, seed):
     depth = int(rng.choice([1, 2, 5, 8, 16]))
     spp = int(rng.choice([1, 3, 4]))
     _check(ctx, random_scene(seed), 96, 54, spp, depth, seed=seed, spp_first=int(rng.integers(0, 3)))
+
+
+@pytest.mark.parametrize("seed", range(100, 108))
+def test_random_scene_mid_size_frame(ctx, seed):
+    """The same at 320 x 180 x 3 spp (172 800 paths): above the tail kernel's threshold at first, so the random
+    materials, media and lights also pass through the wavefront rounds, the mixed launches, the moving compaction
+    into the dense regions and then the tail kernel."""
+    img, st, _ = _check(ctx, random_scene(seed), 320, 180, 3, 12, seed=seed)
+    assert st.launches_extend >= 1 and st.launches_shadow >= 1 and st.launches_tail >= 2  # mixed launch(es) + tail kernel
