@@ -99,3 +99,41 @@ def test_random_scene_mid_size_frame(ctx, seed):
     into the dense regions and then the tail kernel."""
     img, st, _ = _check(ctx, random_scene(seed), 320, 180, 3, 12, seed=seed)
     assert st.launches_extend >= 1 and st.launches_shadow >= 1 and st.launches_tail >= 2  # mixed launch(es) + tail kernel
+
+
+@pytest.mark.parametrize("seed", range(200, 232))
+def test_random_scene_intersector(ctx, seed):
+    """rt_trace_closest / rt_trace_any on the random scenes: random rays over random t ranges (finite, infinite, a
+    negative t_min), the culling kernels and both counting kernels against the oracle's Engine::hit / hit_bool."""
+    import oracle_binding as ob
+    rng = np.random.default_rng(seed)
+    desc = random_scene(seed)
+    scene = rt.Scene(desc)
+    ctx.upload(scene)
+    orc = ob.OracleScene(desc)
+    n = 3000
+    org = rng.uniform(-4.0, 4.0, (n, 3)).astype(np.float32)
+    tgt = rng.uniform(-2.5, 2.5, (n, 3)).astype(np.float32)
+    dr = tgt - org
+    dr = (dr / np.linalg.norm(dr, axis=1, keepdims=True)).astype(np.float32)
+    dr[: n // 10] *= np.float32(rng.uniform(0.3, 3.0))  # unnormalised directions are taken as they are
+    o2, d2 = scenes.pixel_center_rays(scene.flat.camera, 48, 27)
+    org, dr = np.concatenate([org, o2]).astype(np.float32), np.concatenate([dr, d2]).astype(np.float32)
+    t_min, t_max = [(1e-3, np.inf), (0.0, float(rng.uniform(2.0, 9.0))), (float(rng.uniform(0.5, 3.0)), np.inf),
+                    (-5.0, float(rng.uniform(1.0, 6.0)))][seed % 4]
+    o = orc.trace_closest(org, dr, t_min, t_max)
+    oa = orc.trace_any(org, dr, t_min, t_max)
+    for counters, mode in ((False, None), (True, rt.api.COUNT_REFERENCE), (True, rt.api.COUNT_FETCHES)):
+        if mode is not None:
+            ctx.set_visit_count_mode(mode)
+        g = ctx.trace_closest(org, dr, t_min, t_max, counters=counters)
+        for k in ("obj", "prim", "front_face"):
+            assert np.array_equal(g[k], o[k]), (counters, mode, k)
+        for k in ("t", "nx", "ny", "nz"):
+            assert np.array_equal(g[k].view(np.uint32), o[k].view(np.uint32)), (counters, mode, k)
+        ga = ctx.trace_any(org, dr, t_min, t_max, counters=counters)
+        assert np.array_equal(ga["occluded"], oa["occluded"]), (counters, mode)
+        if mode == rt.api.COUNT_REFERENCE:
+            assert np.array_equal(g["n_int"], o["n_int"]) and np.array_equal(g["n_tri"], o["n_tri"])
+            assert np.array_equal(ga["n_int"], oa["n_int"]) and np.array_equal(ga["n_tri"], oa["n_tri"])
+    ctx.set_visit_count_mode(rt.api.COUNT_REFERENCE)
