@@ -2,7 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -42,15 +41,8 @@ int on_exception(const char* who) noexcept;  // host/mesh.cpp: maps the exceptio
 #ifndef RT_WAVES_EU_LEAN_ANY
 #define RT_WAVES_EU_LEAN_ANY 7
 #endif
-#ifndef RT_WAVES_EU_WIDE
-#define RT_WAVES_EU_WIDE 6  // the 4-wide node step holds seven 16-byte loads and four slab tests in flight
-#endif
-#ifndef RT_WAVES_EU_WIDE_ANY
-#define RT_WAVES_EU_WIDE_ANY 7  // the any-hit wide loop fits 72 registers without spills
-#endif
-// lean kernels are templates over WIDE (a bool in scope where these are used)
-#define RT_TRACE_ATTR_LEAN __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? RT_WAVES_EU_WIDE : RT_WAVES_EU_LEAN)))
-#define RT_TRACE_ATTR_LEAN_ANY __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? RT_WAVES_EU_WIDE_ANY : RT_WAVES_EU_LEAN_ANY)))
+#define RT_TRACE_ATTR_LEAN __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_LEAN)))
+#define RT_TRACE_ATTR_LEAN_ANY __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_LEAN_ANY)))
 constexpr int RT_BLOCK = 256;      // threads per workgroup in the traversal kernels (4 waves)
 #ifndef RT_STACK_LDS_N
 #define RT_STACK_LDS_N 24
@@ -86,7 +78,6 @@ struct rt_ctx {
     uint32_t features = 0;  // rtd::SceneFeatures the uploaded scene needs
     rtd::DScene scene{};  // host copy of the kernel argument
     DevBuf pairs, objects, materials, lights, media, wbox;  // pairs: child pairs + triangles (one allocation)
-    DevBuf wide;          // 4-wide nodes (device_scene.h: DWide)
     DevBuf overflow;      // traversal-stack overflow strips
     uint32_t overflow_levels = 0;
     DevBuf staging[16];   // rt_trace_* host<->device staging
@@ -118,16 +109,6 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
 inline bool rt_scene_is_lean(const rt_ctx* ctx) {
     return (ctx->features & ~RT_LEAN_FEAT) == 0 &&
            (RT_LEAN_OVERFLOW || ctx->scene.stack_need <= (uint32_t)(RT_STACK_LEAN < RT_STACK_LEAN_ANY ? RT_STACK_LEAN : RT_STACK_LEAN_ANY));
-}
-
-// RT_WIDE=1: the timed (non-counting) lean kernels walk the 4-wide nodes instead of the child pairs.  Bit-identical
-// and slower (profiles/r03/tuning.md section 1): off by default.
-inline bool rt_use_wide(const rt_ctx* ctx) {
-    static const bool on = [] {
-        const char* e = getenv("RT_WIDE");
-        return e && e[0] == '1';
-    }();
-    return on && ctx->scene.wide != nullptr;
 }
 
 // Scheduler parameters of the persistent trace kernels for a launch of n rays on `grid` blocks.

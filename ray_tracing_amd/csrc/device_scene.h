@@ -28,25 +28,6 @@ struct __attribute__((aligned(64))) DPair {
     DNode c[2];
 };
 
-// 4-WIDE node (128 bytes, 128-byte aligned) of the timed kernels: node W(P) of an internal node P of the reference's
-// tree holds the GRANDCHILDREN of P -- slots 0, 1 = the children of P's first child, slots 2, 3 = those of its
-// second child -- with their exact f32 boxes; a child of P that is itself a leaf sits in the even slot of its group
-// and the odd slot is empty (ref = WIDE_EMPTY, lower = +inf, upper = -inf).  One aligned fetch (seven 16-byte loads)
-// does the work of up to three child-pair fetches, and a ray's chain of DEPENDENT fetches is about half as long
-// (device_trace.h says why the results stay the reference's bit for bit).  A slot's ref is LEAF_BIT | first triangle
-// or the index of the slot's own wide node.  Float layout: slot s at [6 s, 6 s + 6) = lower xyz, upper xyz; the four
-// refs at floats 24..27; floats 28..31 unused (never loaded).
-struct __attribute__((aligned(128))) DWide {
-    float box[24];
-    uint32_t ref[4];
-    uint32_t pad[4];
-};
-constexpr uint32_t WIDE_EMPTY = 0xFFFFFFFFu;
-// traversal-stack words of the wide walk: a DEFERRED entry is (entry distance, ref | WIDE_DEFER), a deferred PAIR
-// (far entry distance, far ref, near entry distance, near ref | WIDE_DEFER | WIDE_PAIR); both bits are free in a ref
-// (< 2^25 wide nodes, < 2^27 triangles in the 4 GiB windows)
-constexpr uint32_t WIDE_DEFER = 0x40000000u, WIDE_PAIR = 0x20000000u;
-
 struct DObject {
     uint32_t kind;           // enum rt_surface_kind
     uint32_t root_ref;       // RT_SURF_MESH: child reference of the root node
@@ -57,7 +38,7 @@ struct DObject {
     float inv_t[3];
     int32_t medium_inside, medium_outside;
     uint32_t has_medium_interface;
-    uint32_t root_wide;      // RT_SURF_MESH: the root as a reference into the 4-wide nodes (a leaf root: = root_ref)
+    uint32_t pad;
 };
 
 struct DScene {
@@ -70,8 +51,7 @@ struct DScene {
     uint32_t n_objects, n_lights, n_media, n_materials;
     rt_camera_flat camera;
     int32_t initial_medium;
-    uint32_t stack_need;  // deepest traversal stack any mesh of the scene can need (binary walk: one word per level)
-    uint32_t stack_need_wide;  // bound on the stack WORDS of the 4-wide walk
+    uint32_t stack_need;  // deepest traversal stack any mesh of the scene can need
     uint32_t tri_off;     // byte offset of tris from pairs (one allocation, < 4 GiB, 64 B of slack after it)
     // Top level over OBJECTS (flat): world-space bounds of up to 64 groups of 2^cull_shift consecutive objects (one
     // object per group in scenes of at most 64), 8 floats each (lower xyz, upper xyz, 2 unused); bit g of cull_test =
@@ -80,7 +60,6 @@ struct DScene {
     const float* wbox;
     unsigned long long cull_test;
     uint32_t cull_shift;
-    const DWide* wide;    // 4-wide nodes of every mesh (own allocation, < 4 GiB); null when the scene has none
 };
 
 // The same records seen through the CONSTANT address space: a load through these with a wave-uniform index
@@ -143,34 +122,6 @@ RT_DEV bool aabb_hit(P lo, P hi, V3 o, V3 inv, float t_min, float t_max, float* 
         float t0 = (lo[2] - o.z) * inv.z, t1 = (hi[2] - o.z) * inv.z;
         bool neg = inv.z < 0.0f;
         t_min = fmaxf(t_min, neg ? t1 : t0);
-        t_max = fminf(t_max, neg ? t0 : t1);
-    }
-    *t_entry = t_min;
-    return !(t_max <= t_min);
-}
-
-// The same test, also handing out the three per-axis NEAR slab distances (the values that enter the running t_min).
-RT_DEV bool aabb_hit_nears(const float* b /* lower xyz, upper xyz */, V3 o, V3 inv, float t_min, float t_max, float* t_entry,
-                           V3* nears) {
-    {
-        float t0 = (b[0] - o.x) * inv.x, t1 = (b[3] - o.x) * inv.x;
-        bool neg = inv.x < 0.0f;
-        nears->x = neg ? t1 : t0;
-        t_min = fmaxf(t_min, nears->x);
-        t_max = fminf(t_max, neg ? t0 : t1);
-    }
-    {
-        float t0 = (b[1] - o.y) * inv.y, t1 = (b[4] - o.y) * inv.y;
-        bool neg = inv.y < 0.0f;
-        nears->y = neg ? t1 : t0;
-        t_min = fmaxf(t_min, nears->y);
-        t_max = fminf(t_max, neg ? t0 : t1);
-    }
-    {
-        float t0 = (b[2] - o.z) * inv.z, t1 = (b[5] - o.z) * inv.z;
-        bool neg = inv.z < 0.0f;
-        nears->z = neg ? t1 : t0;
-        t_min = fmaxf(t_min, nears->z);
         t_max = fminf(t_max, neg ? t0 : t1);
     }
     *t_entry = t_min;

@@ -110,31 +110,10 @@ template <class IO> struct ParksLanes<IO, true> { static constexpr bool value = 
 // (root-box skip and cull active), i.e. the fetches the roofline figure prices.
 enum CountMode { COUNT_NONE = 0, COUNT_REFERENCE = 1, COUNT_FETCHES = 2 };
 
-// WIDE: walk the 4-wide nodes (DWide) instead of the child pairs.  The walk tests the SAME triangles in the SAME order
-// with the SAME running t_max as traverse_bvh (bvh.rs:243-300), so hit, primitive and t are the reference's bits
-// also where two hits tie or a box test and a triangle test disagree by a rounding (oracle/wide_model.cpp holds
-// the CPU model of this walk and tests/test_wide_model.py compares it with the reference's, test sequence for
-// test sequence).  At W(P) the four grandchild boxes are tested with the current t_max T:
-//   * the boxes of P's two children are not stored and not needed for the hits: a child's box contains its
-//     children's bound for bound and AABB::hit is monotone in the bounds, so a grandchild that passes implies its
-//     parent passes (same argument as the root-box skip below);
-//   * the ORDER is the reference's: the child of P visited first is child 1 unless t1 > t2, where t_i is the entry
-//     distance of child i's box -- the union of its two slots (the builder grows a node's box over its primitives
-//     with exact min / max, bvh.rs:89-100, so the union IS the stored box), whose near planes go through the
-//     reference's own slab arithmetic; inside a group the slot visited first is the first unless its entry
-//     distance is larger;
-//   * the slots of the child visited SECOND are box-tested by the reference only when that child is popped, with
-//     the t_max T' <= T of that moment.  Internal slots need no second test (their own slots all fail when they
-//     would have failed, by the containment argument; a wasted fetch, never a different triangle).  LEAF slots do:
-//     they are pushed DEFERRED with their entry distance and tested again at the pop -- !(min(T', exit) <= entry)
-//     is !(T' <= entry) && !(exit0 <= entry) with exit0 free of t_max, and the second factor held at the push --
-//     both slots of the group at the same moment (a deferred PAIR), as the reference tests them together.
-// Any-hit rays never shrink t_max: nothing is deferred.  Visit counters are not kept (COUNT must be 0).
-template <int MODE, int COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, bool OVERFLOW = true, bool WIDE = false, class IO>
+template <int MODE, int COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, bool OVERFLOW = true, class IO>
 RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
                        float t_max_in, uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride) {
     constexpr bool PATH = MODE == TRACE_PATH;
-    static_assert(!WIDE || COUNT == COUNT_NONE, "the 4-wide walk keeps no visit counters");
     // A policy whose rays have no continuation (k_mixed: two kinds of ray, each finished for good) is served at
     // once like the single-kind kernels; only a policy that may hand the lane its NEXT ray parks it for phase D.
     constexpr bool PARK = ParksLanes<IO, PATH>::value;
@@ -229,35 +208,6 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         if (rem == 0ull) return sc.n_objects;
         const uint32_t g2 = (uint32_t)__builtin_ctzll(rem);
         return g2 == g ? from : g2 << sc.cull_shift;
-    };
-
-    // next node of the current tree from the stack (REF_ADVANCE when it is empty).  WIDE: a deferred entry is the
-    // moment the reference pops the far child of P and box-tests ITS children with the t_max of now: the near one is
-    // visited, the far one goes back as a plain entry (a popped node is never tested again, bvh.rs:251-253).
-    auto pop_next = [&]() -> uint32_t {
-        if constexpr (!WIDE) {
-            return st.sp == 0 ? REF_ADVANCE : st.pop();
-        } else {
-            for (;;) {
-                if (st.sp == 0) return REF_ADVANCE;
-                uint32_t v = st.pop();
-                if ((v & WIDE_DEFER) == 0u) return v;
-                const float e_near = __uint_as_float(st.pop());
-                const bool near_ok = !(tmax <= e_near);
-                uint32_t far = 0u;
-                bool far_ok = false;
-                if (v & WIDE_PAIR) {
-                    far = st.pop();
-                    far_ok = !(tmax <= __uint_as_float(st.pop()));
-                }
-                v &= ~(WIDE_DEFER | WIDE_PAIR);
-                if (near_ok) {
-                    if (far_ok) st.push(far);
-                    return v;
-                }
-                if (far_ok) return far;
-            }
-        }
     };
 
     for (;;) {
@@ -443,7 +393,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                         }
                         if (enter) {
                             tmax = t_lim;
-                            cur = WIDE ? ob.root_wide : ob.root_ref;
+                            cur = ob.root_ref;
                             st.sp = 0;
                             pending = false;
                         }
@@ -489,85 +439,6 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
 #define RT_NODE_REPS 3
 #endif
         if (run_node) {
-          if constexpr (WIDE) {
-#ifndef RT_WIDE_REPS
-#define RT_WIDE_REPS 2
-#endif
-            for (int rep = 0; rep < RT_WIDE_REPS; ++rep)
-            if (ray != RAY_NONE && (cur & LEAF_BIT) == 0u) {
-                const uint32_t off = cur << 7;
-                const float4 q0 = ld16(sc.wide, off), q1 = ld16(sc.wide, off + 16u), q2 = ld16(sc.wide, off + 32u),
-                             q3 = ld16(sc.wide, off + 48u), q4 = ld16(sc.wide, off + 64u), q5 = ld16(sc.wide, off + 80u),
-                             q6 = ld16(sc.wide, off + 96u);
-                const uint32_t r0 = __float_as_uint(q6.x), r1 = __float_as_uint(q6.y), r2 = __float_as_uint(q6.z),
-                               r3 = __float_as_uint(q6.w);
-                // One group at a time, so that a group's boxes are dead before the next one's are needed (the step's
-                // register count sets the occupancy of the whole loop).  Per group: the two slot tests and the entry
-                // distance of the box of P's child (bvh.rs:273-274's t1 / t2) -- the union of the two slots, built
-                // plane by plane for the near side only and put through the reference's own slab arithmetic (an
-                // empty odd slot, +inf / -inf, leaves the union at the even slot's planes).
-                // An empty slot never counts as hit, whatever a NaN ray makes of its infinite bounds.
-                float e0, e1, e2, e3, E1, E2;
-                bool h0, h1, h2, h3;
-                const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
-                {
-                    const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y}, b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-                    h0 = aabb_hit(b0, b0 + 3, o, inv, t_min, tmax, &e0);
-                    h1 = aabb_hit(b1, b1 + 3, o, inv, t_min, tmax, &e1) && r1 != WIDE_EMPTY;
-                    const float ux = ngx ? fmaxf(b0[3], b1[3]) : fminf(b0[0], b1[0]);
-                    const float uy = ngy ? fmaxf(b0[4], b1[4]) : fminf(b0[1], b1[1]);
-                    const float uz = ngz ? fmaxf(b0[5], b1[5]) : fminf(b0[2], b1[2]);
-                    E1 = fmaxf(fmaxf(fmaxf(t_min, (ux - o.x) * inv.x), (uy - o.y) * inv.y), (uz - o.z) * inv.z);
-                }
-                {
-                    const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y}, b3[6] = {q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
-                    h2 = aabb_hit(b2, b2 + 3, o, inv, t_min, tmax, &e2);
-                    h3 = aabb_hit(b3, b3 + 3, o, inv, t_min, tmax, &e3) && r3 != WIDE_EMPTY;
-                    const float ux = ngx ? fmaxf(b2[3], b3[3]) : fminf(b2[0], b3[0]);
-                    const float uy = ngy ? fmaxf(b2[4], b3[4]) : fminf(b2[1], b3[1]);
-                    const float uz = ngz ? fmaxf(b2[5], b3[5]) : fminf(b2[2], b3[2]);
-                    E2 = fmaxf(fmaxf(fmaxf(t_min, (ux - o.x) * inv.x), (uy - o.y) * inv.y), (uz - o.z) * inv.z);
-                }
-                const bool g1 = h0 || h1, g2 = h2 || h3;
-                // group A is visited first, group B second (bvh.rs:287-295 at P)
-                const bool second_first = g2 && (!g1 || E1 > E2);
-                const uint32_t a0r = second_first ? r2 : r0, a1r = second_first ? r3 : r1;
-                const uint32_t c0r = second_first ? r0 : r2, c1r = second_first ? r1 : r3;
-                const float a0e = second_first ? e2 : e0, a1e = second_first ? e3 : e1;
-                const float c0e = second_first ? e0 : e2, c1e = second_first ? e1 : e3;
-                const bool ha0 = second_first ? h2 : h0, ha1 = second_first ? h3 : h1;
-                const bool hc0 = second_first ? h0 : h2, hc1 = second_first ? h1 : h3;
-                // inside a group (bvh.rs:287-295 at the child): both hit -> the first unless its entry distance is larger
-                const bool bothA = ha0 && ha1, swA = bothA && a0e > a1e;
-                const uint32_t nearA = (ha1 && (!ha0 || swA)) ? a1r : a0r, farA = swA ? a0r : a1r;
-                const bool okA = ha0 || ha1;
-                const bool bothB = hc0 && hc1, swB = bothB && c0e > c1e;
-                const bool nearB_is1 = hc1 && (!hc0 || swB);
-                const uint32_t nearB = nearB_is1 ? c1r : c0r, farB = swB ? c0r : c1r;
-                const float nearBe = nearB_is1 ? c1e : c0e, farBe = swB ? c0e : c1e;
-                const bool okB = okA && (hc0 || hc1);
-                if (okB) {
-                    // group B = the children of P's far child (unless that child is itself a leaf: odd slot empty)
-                    const bool defer = !any && c1r != WIDE_EMPTY;
-                    if (defer && bothB && (farB & LEAF_BIT) != 0u) {
-                        st.push(__float_as_uint(farBe));
-                        st.push(farB);
-                        st.push(__float_as_uint(nearBe));
-                        st.push(nearB | WIDE_DEFER | WIDE_PAIR);
-                    } else {
-                        if (bothB) st.push(farB);
-                        if (defer && (nearB & LEAF_BIT) != 0u) {
-                            st.push(__float_as_uint(nearBe));
-                            st.push(nearB | WIDE_DEFER);
-                        } else {
-                            st.push(nearB);
-                        }
-                    }
-                }
-                if (bothA) st.push(farA);
-                cur = okA ? nearA : pop_next();
-            }
-          } else {
             // Several node steps per scheduling decision: the ballots, counts and branches around a step
             // cost about as many scalar instructions as the step itself (PMC: 90 SALU against 100 VALU per
             // iteration), and 4 steps in 5 are node steps.  Lanes that leave the node state sit out the
@@ -602,9 +473,8 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                 const bool swap = t1 > t2;
                 cur = (h2 && (!h1 || swap)) ? ref2 : ref1;
                 if (h1 && h2) st.push(swap ? ref1 : ref2);
-                if (!(h1 || h2)) cur = pop_next();
+                if (!(h1 || h2)) cur = st.sp == 0 ? REF_ADVANCE : st.pop();
             }
-          }
         }
 
         RT_CYC(2)
@@ -632,7 +502,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                     ++k;
                 }
                 if (occluded) finish(true);
-                else cur = pop_next();
+                else cur = st.sp == 0 ? REF_ADVANCE : st.pop();
             }
         }
         RT_CYC(3)

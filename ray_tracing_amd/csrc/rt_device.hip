@@ -1,6 +1,5 @@
 // Device context, scene upload and the batch intersector entry points (rt_trace_closest /
 // rt_trace_any).  gfx950 only; compiled with -ffp-contract=off (see device_math.h).
-#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -131,13 +130,13 @@ __global__ RT_TRACE_ATTR void k_trace(DScene sc, TraceIO io, uint32_t n, float t
 }
 
 // lean form (scenes without analytic sphere / triangle objects, rtd::SceneFeatures): 6 waves per SIMD
-template <bool ANY, bool WIDE>
+template <bool ANY>
 __global__ RT_TRACE_ATTR_LEAN void k_trace_lean(DScene sc, TraceIO io, uint32_t n, float t_min, float t_max,
                                                 uint32_t* work_counter, TraceTune tune, uint32_t* overflow,
                                                 uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    trace_loop<ANY ? TRACE_ANY : TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW, WIDE>(
+    trace_loop<ANY ? TRACE_ANY : TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
         sc, io, n, work_counter, tune, t_min, t_max, lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
 
@@ -278,7 +277,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->pairs, &ctx->wide, &ctx->objects, &ctx->materials, &ctx->lights, &ctx->media, &ctx->wbox,
+    DevBuf* bufs[] = {&ctx->pairs, &ctx->objects, &ctx->materials, &ctx->lights, &ctx->media, &ctx->wbox,
                       &ctx->overflow, &ctx->path_state, &ctx->queues, &ctx->counters, &ctx->sample_sum};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->staging) b.release();
@@ -312,9 +311,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) try {
         return RT_ERR_LIMIT;
     }
     std::vector<float4> tris((size_t)s->n_tris * 3);
-    std::vector<uint32_t> root_ref(s->n_bvhs), root_wide(s->n_bvhs);
-    std::vector<DWide> wide;   // 4-wide nodes of the timed kernels (device_scene.h)
-    uint32_t stack_need = 0, stack_need_wide = 0;
+    std::vector<uint32_t> root_ref(s->n_bvhs);
+    uint32_t stack_need = 0;
     for (uint32_t t = 0; t < s->n_tris; ++t) {
         const float *a = s->tri_v0 + 3 * (size_t)t, *b = s->tri_v1 + 3 * (size_t)t, *c = s->tri_v2 + 3 * (size_t)t;
         float4 q0, q1, q2;
@@ -393,72 +391,6 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) try {
         }
         root_ref[bi] = ref_of(0);
         if (depth_max > stack_need) stack_need = depth_max;
-
-        // ---- the same tree as 4-wide nodes: W(P) for the root and for every internal node that is a grandchild
-        // slot of a wide node, numbered depth-first (slot 0's subtree first), so a walk down the left spine reads
-        // ascending addresses like the reference's own numbering.  The tree was validated above.
-        root_wide[bi] = root_ref[bi];
-        if (nnp[0] == 0) {
-            std::vector<uint32_t> wide_id(b.node_count, 0xFFFFFFFFu);
-            std::vector<std::pair<uint32_t, uint32_t>> order;  // (node, wide depth), depth-first
-            std::vector<std::pair<uint32_t, uint32_t>> st2;
-            st2.push_back({0u, 0u});
-            const uint32_t wide_base = (uint32_t)wide.size();
-            uint32_t wdepth_max = 0;
-            while (!st2.empty()) {
-                auto [k, wd] = st2.back();
-                st2.pop_back();
-                wide_id[k] = wide_base + (uint32_t)order.size();
-                order.push_back({k, wd});
-                if (wd > wdepth_max) wdepth_max = wd;
-                for (int g = 1; g >= 0; --g) {
-                    const uint32_t c = nidx[k] + (uint32_t)g;
-                    if (nnp[c] > 0) continue;
-                    for (int q = 1; q >= 0; --q) {
-                        const uint32_t gc = nidx[c] + (uint32_t)q;
-                        if (nnp[gc] == 0) st2.push_back({gc, wd + 1u});
-                    }
-                }
-            }
-            if (((uint64_t)wide_base + order.size()) * sizeof(DWide) >= (1ull << 32)) {
-                rth::set_error("rt_upload_scene: more than 4 GiB of 4-wide BVH nodes");
-                return RT_ERR_LIMIT;
-            }
-            wide.resize((size_t)wide_base + order.size());
-            auto fill_slot = [&](DWide& w, int slot, uint32_t node) {
-                const float* up = s->node_upper + 3 * (size_t)(b.node_offset + node);
-                const float* lw = s->node_lower + 3 * (size_t)(b.node_offset + node);
-                for (int a = 0; a < 3; ++a) {
-                    w.box[6 * slot + a] = lw[a];
-                    w.box[6 * slot + 3 + a] = up[a];
-                }
-                w.ref[slot] = nnp[node] > 0 ? ref_of(node) : wide_id[node];
-            };
-            for (const auto& [k, wd] : order) {
-                (void)wd;
-                DWide& w = wide[wide_id[k]];
-                memset(&w, 0, sizeof w);
-                for (int g = 0; g < 2; ++g) {
-                    const uint32_t c = nidx[k] + (uint32_t)g;
-                    if (nnp[c] > 0) {  // a leaf child: even slot of its group, odd slot empty
-                        fill_slot(w, 2 * g, c);
-                        for (int a = 0; a < 3; ++a) {
-                            w.box[6 * (2 * g + 1) + a] = INFINITY;
-                            w.box[6 * (2 * g + 1) + 3 + a] = -INFINITY;
-                        }
-                        w.ref[2 * g + 1] = WIDE_EMPTY;
-                    } else {
-                        fill_slot(w, 2 * g, nidx[c]);
-                        fill_slot(w, 2 * g + 1, nidx[c] + 1u);
-                    }
-                }
-            }
-            root_wide[bi] = wide_id[0];
-            // stack words of the wide walk: a wide node leaves at most 5 behind while its first slot is walked (the
-            // far slot of the first group: 1; a deferred pair of the second group: 4)
-            const uint32_t need = 5u * (wdepth_max + 1u);
-            if (need > stack_need_wide) stack_need_wide = need;
-        }
     }
 
     // ---- objects
@@ -479,7 +411,6 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) try {
                 return RT_ERR_INVALID;
             }
             o.root_ref = root_ref[f.bvh];
-            o.root_wide = root_wide[f.bvh];
         }
         memcpy(o.surf, f.surf, 9 * sizeof(float));
         if (f.surface_kind == RT_SURF_MESH) {
@@ -622,7 +553,6 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) try {
     if (pair_bytes) RT_HIP(hipMemcpyAsync(ctx->pairs.p, pairs.data(), pair_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (tri_bytes)
         RT_HIP(hipMemcpyAsync((char*)ctx->pairs.p + tri_off, tris.data(), tri_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = up(ctx->wide, wide.data(), wide.size() * sizeof(DWide))) != RT_OK) return rc;
     if ((rc = up(ctx->objects, objs.data(), objs.size() * sizeof(DObject))) != RT_OK) return rc;
     if ((rc = up(ctx->wbox, wbox.data(), wbox.size() * sizeof(float))) != RT_OK) return rc;
     if ((rc = up(ctx->materials, s->materials, s->n_materials * sizeof(rt_material))) != RT_OK) return rc;
@@ -648,11 +578,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_flat* s) try {
     d.wbox = (const float*)ctx->wbox.p;
     d.cull_test = cull_test;
     d.cull_shift = cull_shift;
-    d.wide = wide.empty() ? nullptr : (const DWide*)ctx->wide.p;
-    d.stack_need_wide = stack_need_wide;
-    // the overflow strips serve every kernel: the binary walks need one word per level, the wide walk its own bound
-    const uint32_t need_all = std::max(stack_need, stack_need_wide);
-    ctx->overflow_levels = need_all > (uint32_t)RT_STACK_MIN ? need_all - RT_STACK_MIN : 0;
+    ctx->overflow_levels = stack_need > (uint32_t)RT_STACK_MIN ? stack_need - RT_STACK_MIN : 0;
     ctx->features = features;
     ctx->has_scene = true;
 
@@ -712,8 +638,7 @@ int rt_initial_medium(const rt_ctx* ctx, int32_t* out) {
 // One closest-hit / any-hit launch over device-resident arrays: the part rt_trace_* and rt_trace_*_noalloc share.
 // `work` = WORK_U32 zeroed work counters, `overflow` = traversal-stack overflow strips for `lanes` lanes.
 static int launch_trace(rt_ctx* ctx, bool any, const TraceIO& io, size_t n, float t_min, float t_max, int grid,
-                        uint32_t* work, uint32_t* overflow, uint32_t lanes, bool allow_wide = true) {
-    const bool wide = allow_wide && rt_use_wide(ctx);
+                        uint32_t* work, uint32_t* overflow, uint32_t lanes) {
     const bool want_count = io.out.n_int || io.out.n_tri;
     const int count = !want_count ? COUNT_NONE : (ctx->count_mode == RT_COUNT_FETCHES ? COUNT_FETCHES : COUNT_REFERENCE);
     const TraceTune tune = rt_trace_tune(n, grid);
@@ -724,14 +649,12 @@ static int launch_trace(rt_ctx* ctx, bool any, const TraceIO& io, size_t n, floa
     if (any) {
         if (count == COUNT_REFERENCE) RT_LAUNCH_TRACE(k_trace<true, COUNT_REFERENCE>);
         else if (count == COUNT_FETCHES) RT_LAUNCH_TRACE(k_trace<true, COUNT_FETCHES>);
-        else if (rt_scene_is_lean(ctx) && wide) RT_LAUNCH_TRACE(k_trace_lean<true, true>);
-        else if (rt_scene_is_lean(ctx)) RT_LAUNCH_TRACE(k_trace_lean<true, false>);
+        else if (rt_scene_is_lean(ctx)) RT_LAUNCH_TRACE(k_trace_lean<true>);
         else RT_LAUNCH_TRACE(k_trace<true, COUNT_NONE>);
     } else {
         if (count == COUNT_REFERENCE) RT_LAUNCH_TRACE(k_trace<false, COUNT_REFERENCE>);
         else if (count == COUNT_FETCHES) RT_LAUNCH_TRACE(k_trace<false, COUNT_FETCHES>);
-        else if (rt_scene_is_lean(ctx) && wide) RT_LAUNCH_TRACE(k_trace_lean<false, true>);
-        else if (rt_scene_is_lean(ctx)) RT_LAUNCH_TRACE(k_trace_lean<false, false>);
+        else if (rt_scene_is_lean(ctx)) RT_LAUNCH_TRACE(k_trace_lean<false>);
         else RT_LAUNCH_TRACE(k_trace<false, COUNT_NONE>);
     }
 #undef RT_LAUNCH_TRACE
@@ -886,8 +809,7 @@ int rt_trace_closest_noalloc(rt_ctx* ctx, const rt_rays* rays, size_t n, float t
     uint32_t* overflow = ctx->scratch + WORK_U32;  // the strips need no initial value (written before they are read)
     RT_HIP(hipMemsetAsync(work, 0, WORK_U32 * sizeof(uint32_t), ctx->stream));
     TraceIO io{*rays, *hits, nullptr};
-    // the child-pair walk: the static strips are sized for its one word per tree level
-    if ((rc = launch_trace(ctx, false, io, n, t_min, t_max, grid, work, overflow, (uint32_t)NOALLOC_LANES, false)) != RT_OK) return rc;
+    if ((rc = launch_trace(ctx, false, io, n, t_min, t_max, grid, work, overflow, (uint32_t)NOALLOC_LANES)) != RT_OK) return rc;
     RT_HIP(hipStreamSynchronize(ctx->stream));
     RT_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev[0], ctx->ev[1]));
     return RT_OK;

@@ -198,7 +198,6 @@ __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t*
 }
 
 // The same kernel for scenes whose objects are meshes and planes (rtd::SceneFeatures): fewer registers, more waves.
-template <bool WIDE>
 __global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const uint32_t* queue, const uint32_t* counts, uint32_t first,
                                                  uint32_t* work_counter, TuneBase base, uint32_t* overflow,
                                                  uint32_t overflow_stride) {
@@ -207,7 +206,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const
     const uint32_t n = counts[0];
     const TraceTune tune = make_tune(base, n, gridDim.x);
     ExtendIO io{pa, queue, 0ull, 0ull, (first & 1u) != 0u, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
-    trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW, WIDE>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+    trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                                   lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
 
@@ -262,7 +261,6 @@ __global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, const uint3
     if (COUNT) add_visits(&pa.visit[2], io.n_int, io.n_tri);
 }
 
-template <bool WIDE>
 __global__ RT_TRACE_ATTR_LEAN_ANY void k_shadow_lean(DScene sc, PathArrays pa, const uint32_t* counts, uint32_t* work_counter,
                                                      TuneBase base, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN_ANY * RT_BLOCK];
@@ -270,7 +268,7 @@ __global__ RT_TRACE_ATTR_LEAN_ANY void k_shadow_lean(DScene sc, PathArrays pa, c
     const uint32_t n = counts[1];
     const TraceTune tune = make_tune(base, n, gridDim.x);
     ShadowIO io{pa, 0ull, 0ull};
-    trace_loop<TRACE_ANY, false, RT_STACK_LEAN_ANY, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW, WIDE>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
+    trace_loop<TRACE_ANY, false, RT_STACK_LEAN_ANY, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
                                                               lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
 }
 
@@ -679,7 +677,6 @@ __global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays ps, PathArrays pa, c
     }
 }
 
-template <bool WIDE>
 __global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays ps, PathArrays pa, const uint32_t* queue, const uint32_t* counts,
                                                 uint32_t identity, uint32_t* work_counter, TuneBase base, uint32_t* overflow,
                                                 uint32_t overflow_stride) {
@@ -688,7 +685,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays ps, PathAr
     const uint32_t n_shadow = counts[1], n = n_shadow + counts[0];
     const TraceTune tune = make_tune(base, n, gridDim.x);
     MixedIO io{ps, pa, queue, n_shadow, identity != 0u, 0ull, 0ull, 0ull, 0ull};
-    trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW, WIDE>(sc, io, n, work_counter, tune, T_MIN,
+    trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN,
                                                                          __builtin_inff(), lds_stack + threadIdx.x,
                                                                          overflow + gtid, overflow_stride);
 }
@@ -1023,7 +1020,6 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     const bool use_mix = use_tail && mix_paths > 0;
     uint64_t mixed_closest = 0, mixed_shadow = 0;
     const bool lean = rt_scene_is_lean(ctx) && getenv("RT_NO_LEAN") == nullptr;
-    const bool wide = rt_use_wide(ctx);  // the 4-wide walk (device_trace.h) in the timed kernels
     static const uint32_t tail_paths = [] {  // RT_TAIL_PATHS overrides the switch-over point (experiments)
         const char* e = getenv("RT_TAIL_PATHS");
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 32768u;
@@ -1101,10 +1097,8 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
             hipLaunchKernelGGL(k_extend<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
             hipLaunchKernelGGL(k_extend<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
-        else if (lean && wide)
-            hipLaunchKernelGGL(k_extend_lean<true>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
         else if (lean)
-            hipLaunchKernelGGL(k_extend_lean<false>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_extend_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
         else
             hipLaunchKernelGGL(k_extend<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
     };
@@ -1113,10 +1107,8 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
             hipLaunchKernelGGL(k_shadow<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
             hipLaunchKernelGGL(k_shadow<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
-        else if (lean && wide)
-            hipLaunchKernelGGL(k_shadow_lean<true>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
         else if (lean)
-            hipLaunchKernelGGL(k_shadow_lean<false>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_shadow_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
         else
             hipLaunchKernelGGL(k_shadow<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
     };
@@ -1125,10 +1117,8 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
             hipLaunchKernelGGL(k_mixed<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
             hipLaunchKernelGGL(k_mixed<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
-        else if (lean && wide)
-            hipLaunchKernelGGL(k_mixed_lean<true>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
         else if (lean)
-            hipLaunchKernelGGL(k_mixed_lean<false>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_mixed_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
         else
             hipLaunchKernelGGL(k_mixed<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
     };
@@ -1376,7 +1366,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
 extern "C" int rt_debug_occupancy(int* out4) {  // resident workgroups per CU: extend, shadow, extend_lean, shade
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_extend<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_shadow<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend_lean<true>, RT_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend_lean, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_shade, SHADE_BLOCK, 0) != hipSuccess) return -2;
     return 0;
 }
