@@ -30,13 +30,15 @@ static __device__ unsigned long long g_trace_stats[40];
 #endif
 
 // Launch-time tuning of the wave scheduler (uniform kernel argument).
-constexpr uint32_t WORK_MAX_SEG = 64;     // work counters per launch
+constexpr uint32_t WORK_MAX_SEG = 64;     // work counters per ray kind and launch (a mixed launch has two kinds: 128 segments)
 constexpr uint32_t WORK_STRIDE = 32;      // u32 between counters: one 128-byte line each
 constexpr uint32_t WORK_U32 = WORK_MAX_SEG * WORK_STRIDE;
+constexpr uint32_t WORK_BUF_U32 = 2 * WORK_U32 + 32;  // a launch's work buffer: 128 counters + the two drained masks (own line)
 struct TraceTune {
     uint32_t chunk;       // rays a wave takes from a work counter per atomic
-    uint32_t n_seg;       // the queue is split into n_seg contiguous segments, one counter each
-    uint32_t seg_len;     // rays per segment (multiple of chunk)
+    uint32_t n_seg;       // the queue is split into n_seg segments, one counter each (<= 2 * WORK_MAX_SEG)
+    uint32_t seg_len;     // rays per segment (multiple of chunk); with per-segment counts (trace_loop's seg_counts): the
+                          // distance between the first items of consecutive segments
     uint32_t refill_min;  // idle lanes that trigger a refill
     uint32_t w_adv, w_node, w_leaf;  // phase weights: each loop iteration runs the ONE phase with the largest
                                      // (lanes waiting for it) x weight
@@ -112,7 +114,15 @@ enum CountMode { COUNT_NONE = 0, COUNT_REFERENCE = 1, COUNT_FETCHES = 2 };
 
 template <int MODE, int COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, bool OVERFLOW = true, class IO>
 RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
-                       float t_max_in, uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride) {
+                       float t_max_in, uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride,
+                       const uint32_t* seg_counts = nullptr, uint32_t counter_first = 0u) {
+    // The launch's items: segment s holds items [s * seg_len, s * seg_len + count(s)).  count(s) comes from device
+    // memory (rt_render: the survivors of a bounce are compacted per segment, rt_render.hip) or, without it, the n
+    // items are contiguous and every segment but the last is full.
+    // work_counter: WORK_BUF_U32 zeroed u32 -- 2 * WORK_MAX_SEG counters, one 128-byte line each, then two 64-bit masks of
+    // the counters whose last chunk has been handed out.  Segment s of this launch draws from counter counter_first + s
+    // (rt_render runs a shadow launch on counters 64.. and the next closest-hit launch on counters 0.. between two
+    // resets; a mixed launch uses all 128).
     constexpr bool PATH = MODE == TRACE_PATH;
     // A policy whose rays have no continuation (k_mixed: two kinds of ray, each finished for good) is served at
     // once like the single-kind kernels; only a policy that may hand the lane its NEXT ray parks it for phase D.
@@ -129,7 +139,17 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     uint32_t ray = RAY_NONE;
     bool more = true;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
-    uint32_t seg = blockIdx.x % tune.n_seg, seg_tried = 0;  // wave-uniform
+    auto seg_count = [&](uint32_t s_) -> uint32_t {
+        if (seg_counts) return seg_counts[s_];
+        const unsigned long long first = (unsigned long long)s_ * tune.seg_len;
+        return first >= n ? 0u : (uint32_t)min((unsigned long long)tune.seg_len, (unsigned long long)n - first);
+    };
+    uint32_t seg = blockIdx.x % tune.n_seg;  // wave-uniform: the segment the wave draws from (first: its home segment)
+    // wave-uniform: segments this wave need not ask (again): empty from the start, or found drained
+    unsigned long long dead_lo = __builtin_amdgcn_ballot_w64(lane >= tune.n_seg || seg_count(lane) == 0u);
+    unsigned long long dead_hi = tune.n_seg > 64u ? __builtin_amdgcn_ballot_w64(lane + 64u >= tune.n_seg || seg_count(lane + 64u) == 0u) : ~0ull;
+    uint32_t seg_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_count(seg));  // items of the current segment
+    unsigned long long* const drained = reinterpret_cast<unsigned long long*>(work_counter + 2u * WORK_U32);
     V3 wo = v3(0, 0, 0), wd = wo;                     // world-space ray
     V3 o = wo, d = wo, inv = wo;                      // object-space ray of the current object
     float nr = 1.0f;                                  // |M^-1 d|^-1 of the current object
@@ -226,20 +246,46 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                 // scope atomics on one address complete at the memory side, about one per 15 ns, and
                 // a frame needs 4.4 M of them at chunk 64 (profiles/r01/tuning.md).
                 while (pool_next == pool_end && more) {
-                    uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(work_counter + seg * WORK_STRIDE, chunk);
-                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                    const uint32_t seg_begin = seg * tune.seg_len;
-                    if (b < tune.seg_len && seg_begin + b < n) {
-                        pool_next = seg_begin + b;
-                        pool_end = min(min(pool_next + chunk, seg_begin + tune.seg_len), n);
-                    } else {
-                        seg = seg + 1u == tune.n_seg ? 0u : seg + 1u;
-                        if (++seg_tried == tune.n_seg) more = false;
+                    const uint32_t gseg = counter_first + seg;
+                    uint32_t b = seg_cnt;
+                    if (seg_cnt != 0u) {
+                        if (lane == 0) b = atomicAdd(work_counter + gseg * WORK_STRIDE, chunk);
+                        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    }
+                    const bool last_chunk = b >= seg_cnt || b + chunk >= seg_cnt;
+                    if (b < seg_cnt) {
+                        pool_next = seg * tune.seg_len + b;
+                        pool_end = pool_next + min(chunk, seg_cnt - b);
+                        // whoever takes a segment's last chunk says so to every wave of the launch
+                        if (last_chunk && lane == 0) atomicOr(&drained[gseg >> 6], 1ull << (gseg & 63u));
+                    }
+                    if (last_chunk) {
+                        if (seg < 64u) dead_lo |= 1ull << seg;
+                        else dead_hi |= 1ull << (seg - 64u);
+                    }
+                    if (b >= seg_cnt) {
+                        // Drained.  One look at the launch's drained masks (a load that bypasses the L1; a stale word can
+                        // only send the wave to a segment that is drained too, which it then marks and never asks again)
+                        // instead of one atomic per drained segment and wave: at the end of a launch every wave comes here.
+                        const unsigned long long g_lo = __hip_atomic_load(&drained[counter_first >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long g_hi = tune.n_seg > 64u ? __hip_atomic_load(&drained[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                        const unsigned long long av_lo = ~(dead_lo | g_lo), av_hi = ~(dead_hi | g_hi);
+                        if ((av_lo | av_hi) == 0ull) {
+                            more = false;
+                        } else {  // the first segment with work after this one, cyclically
+                            const uint32_t nx = seg + 1u;
+                            const unsigned long long a_lo = nx < 64u ? av_lo & (~0ull << nx) : 0ull;
+                            const unsigned long long a_hi = nx < 64u ? av_hi : (nx < 128u ? av_hi & (~0ull << (nx - 64u)) : 0ull);
+                            if (a_lo) seg = (uint32_t)__builtin_ctzll(a_lo);
+                            else if (a_hi) seg = 64u + (uint32_t)__builtin_ctzll(a_hi);
+                            else if (av_lo) seg = (uint32_t)__builtin_ctzll(av_lo);
+                            else seg = 64u + (uint32_t)__builtin_ctzll(av_hi);
+                            seg_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_count(seg));
+                        }
                     }
                 }
                 if (more) {
-                    const uint32_t take = min(n_idle, pool_end - pool_next);
+                    const uint32_t take = min(n_idle, pool_end - pool_next);  // pool_end > pool_next here
                     const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
                     if (idle && rank < take) {
                         const uint32_t idx = pool_next + rank;

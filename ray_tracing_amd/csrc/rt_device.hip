@@ -148,7 +148,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_trace_lean(DScene sc, TraceIO io, uint32_t 
 // host code uses that pointer everywhere.  All calls on one GPU share the array: calls that overlap on a GPU race.
 constexpr uint32_t NOALLOC_LEVELS = RT_NOALLOC_MAX_STACK_DEPTH - RT_STACK_MIN;       // overflow levels the strips hold
 constexpr size_t NOALLOC_LANES = (size_t)RT_TRACE_GRID * RT_BLOCK;                   // lanes of the largest trace grid
-constexpr size_t SCRATCH_U32 = WORK_U32 + NOALLOC_LANES * NOALLOC_LEVELS;
+constexpr size_t SCRATCH_U32 = WORK_BUF_U32 + NOALLOC_LANES * NOALLOC_LEVELS;
 static_assert(RT_NOALLOC_MAX_STACK_DEPTH > RT_STACK_MIN, "the allocation-free entry point needs at least one overflow level");
 static __device__ __align__(256) uint32_t scratch[SCRATCH_U32];
 
@@ -636,7 +636,7 @@ int rt_initial_medium(const rt_ctx* ctx, int32_t* out) {
 }
 
 // One closest-hit / any-hit launch over device-resident arrays: the part rt_trace_* and rt_trace_*_noalloc share.
-// `work` = WORK_U32 zeroed work counters, `overflow` = traversal-stack overflow strips for `lanes` lanes.
+// `work` = WORK_BUF_U32 zeroed u32 (work counters + drained masks), `overflow` = traversal-stack overflow strips for `lanes` lanes.
 static int launch_trace(rt_ctx* ctx, bool any, const TraceIO& io, size_t n, float t_min, float t_max, int grid,
                         uint32_t* work, uint32_t* overflow, uint32_t lanes) {
     const bool want_count = io.out.n_int || io.out.n_tri;
@@ -694,8 +694,8 @@ int rt_trace_closest(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, fl
     const int grid = trace_grid(n);
     const size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
-    if ((rc = ctx->counters.ensure(WORK_U32 * 4)) != RT_OK) return rc;
-    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, WORK_U32 * 4, ctx->stream));
+    if ((rc = ctx->counters.ensure(WORK_BUF_U32 * 4)) != RT_OK) return rc;
+    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, WORK_BUF_U32 * 4, ctx->stream));
     TraceIO io{dr, dh, nullptr};
     if ((rc = launch_trace(ctx, false, io, n, t_min, t_max, grid, (uint32_t*)ctx->counters.p, (uint32_t*)ctx->overflow.p,
                            (uint32_t)lanes)) != RT_OK)
@@ -761,8 +761,8 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
     const int grid = trace_grid(n);
     const size_t lanes = (size_t)grid * RT_BLOCK;
     if ((rc = rt_ctx_ensure_overflow(ctx, lanes)) != RT_OK) return rc;
-    if ((rc = ctx->counters.ensure(WORK_U32 * 4)) != RT_OK) return rc;
-    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, WORK_U32 * 4, ctx->stream));
+    if ((rc = ctx->counters.ensure(WORK_BUF_U32 * 4)) != RT_OK) return rc;
+    RT_HIP(hipMemsetAsync(ctx->counters.p, 0, WORK_BUF_U32 * 4, ctx->stream));
     rt_hits dh;
     memset(&dh, 0, sizeof dh);
     dh.n_int = d_ni;
@@ -805,9 +805,9 @@ int rt_trace_closest_noalloc(rt_ctx* ctx, const rt_rays* rays, size_t n, float t
             return RT_ERR_INVALID;
         }
     const int grid = trace_grid(n);
-    uint32_t* work = ctx->scratch;               // [0, WORK_U32): work counters, zeroed per call
-    uint32_t* overflow = ctx->scratch + WORK_U32;  // the strips need no initial value (written before they are read)
-    RT_HIP(hipMemsetAsync(work, 0, WORK_U32 * sizeof(uint32_t), ctx->stream));
+    uint32_t* work = ctx->scratch;               // [0, WORK_BUF_U32): work counters and drained masks, zeroed per call
+    uint32_t* overflow = ctx->scratch + WORK_BUF_U32;  // the strips need no initial value (written before they are read)
+    RT_HIP(hipMemsetAsync(work, 0, WORK_BUF_U32 * sizeof(uint32_t), ctx->stream));
     TraceIO io{*rays, *hits, nullptr};
     if ((rc = launch_trace(ctx, false, io, n, t_min, t_max, grid, work, overflow, (uint32_t)NOALLOC_LANES)) != RT_OK) return rc;
     RT_HIP(hipStreamSynchronize(ctx->stream));

@@ -5,16 +5,18 @@
 //   extend          one lane per live path: Engine::hit (closest hit through the BVH)
 //   shade           one lane per live path: one iteration of the `while depth > 0` loop --
 //                   light hit + MIS, medium majorant step, BSDF sample, NEE set-up, throughput,
-//                   medium switch, Russian roulette; leaves alive / shadow flags
-//   compact         wave64 ballot + prefix sums: stable stream compaction of the live-path queue
-//                   and of the shadow-ray queue (block totals come out of shade)
+//                   medium switch, Russian roulette -- AND the stream compaction: a block counts its
+//                   survivors and shadow rays (wave64 ballots), reserves room for them with one atomic
+//                   and writes their state straight to consecutive positions of the next bounce's region
+//   publish         one wave: turns the reserved totals into the next bounce's counts
 //   shadow-connect  one lane per shadow ray: Engine::hit_bool, adds the pending NEE term
 //   resolve         per pixel, adds the samples of the batch IN SAMPLE ORDER into the frame sum
 //
-// A path keeps one slot (= sample_in_batch * pixels + pixel) for its whole life; queues hold slot
-// ids.  Radiance additions happen in the reference's order (NEE of iteration k before emission of
-// iteration k+1), and every random draw is addressed by (pixel, sample, bounce, draw), so the sum
-// written for a pixel is bit-identical to the sequential CPU loop.
+// A path's identity is its ORIGINAL slot (= pixel * samples + sample): it names the pixel, the sample -- hence the
+// random numbers -- and the radiance record, and it travels with the path's state from region to region.  Radiance
+// additions happen in the reference's order (NEE of iteration k before emission of iteration k+1), and every random
+// draw is addressed by (pixel, sample, bounce, draw), so the sum written for a pixel is bit-identical to the
+// sequential CPU loop whatever order the compaction leaves the paths in.
 #include <cmath>
 #include <cstring>
 
@@ -31,33 +33,52 @@ constexpr int SHADE_BLOCK = 256;
 
 constexpr uint32_t QF_ALIVE = 1u, QF_SHADOW = 2u, QF_SKIPPED = 4u;  // QF_SKIPPED: a shadow ray the reference issues and nobody needs
 
-struct PathArrays {      // SoA over slots
+// Positions.  The paths of a bounce live in NSEG segments of one region: segment s holds its paths at positions
+// [s * seg_cap, s * seg_cap + count[s]), seg_cap = ceil(batch / NSEG).  The survivors of segment s are written to
+// segment s of the OTHER region by k_shade (densely from the segment's first position, in the order the blocks'
+// reservations arrive), the shadow rays of the bounce to segment s of the shadow records.  A segment is a band of the
+// image (positions start out as pixel-major slots), it is what the workgroups of the trace kernels draw their rays
+// from (device_trace.h: one work counter per segment), and it is what keeps the reservations off a single address:
+// a block reserves with ONE 64-bit atomic (survivors | shadow rays << 32) on its segment's accumulator, and
+// consecutive blocks belong to different segments (device-scope atomics on one address complete at the memory side,
+// about one per 15 ns: 518 400 blocks on one address would be 8 ms, on 64 they are 0.12 ms in parallel).
+constexpr uint32_t NSEG = WORK_MAX_SEG;
+static_assert(NSEG == 64, "k_publish is one wave, one lane per segment");
+constexpr uint32_t ACC_STRIDE = 16;  // u64 between accumulators: one 128-byte line each
+// A bounce of n paths uses ns = 2^k <= NSEG segments of stride NSEG / ns * seg_cap (segments_for() on the host: what
+// a launch of n rays wants as work segments, 64 from 8 Mi rays up, one below 256 Ki) -- a small launch over 128 nearly
+// empty segments spends its time on their counters -- and since paths only die, ns only shrinks from bounce to bounce: a
+// segment of the next bounce is the union of consecutive segments of this one, so its stride always holds them.
+// counts block (u32), two of them, ping-pong over the bounces: [0, NSEG) shadow rays per segment of the bounce BEFORE
+// this one, [NSEG, 2 NSEG) paths alive per segment at this bounce, the totals, and at CNT_MIXED the 2 ns segments of a
+// mixed launch in its order (shadow rays of the ns segments, then the paths of the ns segments)
+constexpr uint32_t CNT_SHADOW = 0, CNT_ALIVE = NSEG, CNT_TOT_ALIVE = 2 * NSEG, CNT_TOT_SHADOW = 2 * NSEG + 1, CNT_MIXED = 2 * NSEG + 4,
+                   CNT_U32 = 4 * NSEG + 4;
+
+struct PathArrays {      // the arrays one bounce works on (all indexed by POSITION unless noted)
     // 16-byte records; the w lanes carry the scalar path state, so a bounce moves 3 records per path
     // in and 3 out (the bounce number is the wavefront iteration: a kernel argument, not path state)
     float4* ray_o;       // origin.xyz, bits: current medium (int) << 1 | previous bounce was specular
     float4* ray_d;       // direction.xyz, prev_pdf
     float4* beta;        // throughput.xyz, bits: depth (u32; wraps like the reference's, path_integrator.rs:193)
-    float4* rad;         // radiance.xyz, -   ALWAYS indexed by the path's original slot (k_resolve sums it in sample order)
-    uint32_t* oid;       // original slot (= sample_in_batch * pixels + pixel: names the pixel, the sample and the rad
-                         // record) of the path in each slot of a DENSE region; null in the first region, where slot = id
+    uint32_t* oid;       // the path's original slot; null at the first bounce, where position = slot
+    float4 *nray_o, *nray_d, *nbeta;  // the same three records in the region the survivors go to ...
+    uint32_t* noid;                   // ... with their original slot
+    float4* rad;         // radiance.xyz, -   indexed by ORIGINAL SLOT (k_resolve sums it in sample order)
     float4* hit_a;       // t, normal.xyz (normal of analytic surfaces only)
     uint2* hit_b;        // obj | front_face<<31 (RT_MISS = no hit), triangle slot of a mesh hit (normal: shade_path)
-    float4* sh_d;        // shadow direction.xyz, - (the shadow ray starts at ray_o: the vertex just shaded)
+    float4* sh_o;        // shadow ray: origin.xyz (the vertex just shaded), bits: original slot
+    float4* sh_d;        // shadow direction.xyz, -
     float4* sh_c;        // pending NEE term.xyz, apply flag
-    uint32_t* queue[2];  // live-path queues (ping-pong)
-    uint32_t* shadow_q;
-    uint32_t* qflags;    // per queue position: QF_* of the path there
-    uint32_t* block_cnt; // [2][blocks]: alive, shadow totals per shade block
-    uint32_t* block_off; // [2][blocks]: exclusive scan inside the block's scan group
-    uint32_t* group_tot; // [2][groups]: totals of each group of SCAN_GROUP blocks
-    uint32_t* group_off; // [2][groups]: exclusive scan of the group totals
-    uint32_t* counts;    // [2][4], ping-pong over the bounces: [0] live paths of the bounce, [1] shadow rays of the bounce
-                         // before it.  Every kernel reads its n from here: the host enqueues a bounce before it knows how
-                         // many paths survived the previous one (rt_render below).
-    uint32_t* counts_host;  // the same two numbers per bounce, written by k_compact_scan_top into pinned host memory
-    uint32_t max_blocks, max_groups;  // strides of block_cnt / block_off and group_tot / group_off
-    uint32_t* work;      // extend work counters [0, WORK_U32), shadow work counters [WORK_U32, 2*WORK_U32); zeroed by
-                         // k_compact_scan_top of every bounce
+    const uint32_t* cnt; // counts block of this bounce (CNT_*)
+    unsigned long long* acc;  // [NSEG * ACC_STRIDE] reservations of this bounce: survivors | shadow rays << 32 per segment
+    uint32_t* acc_skipped;    // shadow rays of this bounce that nobody needs (a total)
+    uint32_t ns, seg_stride;          // segments of this bounce's paths (and of the shadow records traced with them) and their stride
+    uint32_t ns_out, out_stride;      // segments the survivors and the shadow rays of this bounce go to
+    uint32_t n_positions;             // NSEG * seg_cap = ns * seg_stride: items of a mixed launch below it are shadow records
+    uint32_t* work;      // WORK_BUF_U32 (device_trace.h), zeroed by k_publish of every bounce: closest-hit launches (and the
+                         // tail kernel) use the first NSEG counters, shadow launches the second NSEG, a mixed launch all of
+                         // them (its 2 NSEG segments in order) -- each counter serves one launch per bounce
     unsigned long long* tail;   // k_tail totals (see k_tail)
     unsigned long long* visit; // [0] n_int extend, [1] n_tri extend, [2] n_int shadow, [3] n_tri shadow
 };
@@ -71,7 +92,6 @@ struct RenderParams {
     uint32_t k0, k1;        // Philox key = seed
     uint32_t bounce;        // k_shade: RNG bounce index of this wavefront iteration (= iteration + 1)
     uint32_t skip_zero_nee;   // do not trace shadow rays whose light term is exactly zero (not when counting the reference's visits)
-    uint32_t identity_queue;  // queue position i holds slot i (first bounce; every bounce after a moving compaction): no look-up
     uint32_t implicit_first;  // the first bounce's origin, throughput, depth and medium are the same for every
                               // path (camera origin, 1, rp.depth, initial medium): k_generate does not store
                               // them and the first extend / shade do not load them (64 B per path less traffic)
@@ -99,13 +119,20 @@ RT_DEV float pack_medium(int medium, bool prev_specular) {
 }
 
 // ---------------------------------------------------------------- generate
-__global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, RenderParams rp, uint32_t n_paths, rt_rays ur) {
+// Position = slot: every segment but the last starts full.  Block 0 also writes the counts of bounce 0.
+__global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, RenderParams rp, uint32_t n_paths, rt_rays ur,
+                                                  uint32_t* cnt0) {
     uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    if (slot >= n_paths) return;
-    if (slot == 0) {  // bounce 0: every path is alive, no shadow rays pending
-        pa.counts[0] = n_paths;
-        pa.counts[1] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < NSEG) {  // bounce 0: every path is alive, no shadow rays pending
+        const unsigned long long first = (unsigned long long)threadIdx.x * pa.seg_stride;
+        cnt0[CNT_ALIVE + threadIdx.x] = (threadIdx.x >= pa.ns || first >= n_paths) ? 0u : (uint32_t)min((unsigned long long)pa.seg_stride, n_paths - first);
+        cnt0[CNT_SHADOW + threadIdx.x] = 0u;
+        if (threadIdx.x == 0) {
+            cnt0[CNT_TOT_ALIVE] = n_paths;
+            cnt0[CNT_TOT_SHADOW] = 0u;
+        }
     }
+    if (slot >= n_paths) return;
     uint32_t pixel, s_local;
     slot_pixel(rp, slot, &pixel, &s_local);
     V3 origin, dir;
@@ -129,7 +156,6 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
     }
     pa.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
     pa.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    // no queue entry: the first bounce's queue is the identity and nobody looks it up (RenderParams::identity_queue)
 }
 
 // ---------------------------------------------------------------- extend
@@ -144,79 +170,87 @@ RT_DEV void add_visits(unsigned long long* dst, unsigned long long a, unsigned l
     }
 }
 
-struct ExtendIO {  // rays come from the live-path queue, hits go to the path's slot
+struct ExtendIO {  // ray i = the path at position i; hits go to the position's hit record
     PathArrays pa;
-    const uint32_t* queue;
     unsigned long long n_int, n_tri;
     bool first;       // first bounce with implicit state (RenderParams::implicit_first): every ray starts at the camera
-    bool identity;    // queue position = slot (first bounce, and after a moving compaction)
     float cam[3];     // ... whose origin travels by value (a pointer into the kernel arguments turns the load of the
                       // origin into a flat load of a selected address)
-    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // returns the path's slot: the ray's tag from here on
-        const uint32_t slot = identity ? i : queue[i];
-        float4 d4 = pa.ray_d[slot];
+    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // returns the position: the ray's tag from here on
+        float4 d4 = pa.ray_d[i];
         if (first) {  // uniform
             *o = v3(cam[0], cam[1], cam[2]);
         } else {
-            float4 o4 = pa.ray_o[slot];
+            float4 o4 = pa.ray_o[i];
             *o = v3(o4.x, o4.y, o4.z);
         }
         *d = v3(d4.x, d4.y, d4.z);
-        return slot;
+        return i;
     }
     // a closer hit than any before it on this ray (Engine::hit's `closest = Some(..)`, :92-94)
-    RT_DEV void hit(uint32_t slot, float t, V3 n, uint32_t meta, uint32_t prim) const {
-        pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
-        pa.hit_b[slot] = make_uint2(meta, prim);
+    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
+        pa.hit_a[i] = make_float4(t, n.x, n.y, n.z);
+        pa.hit_b[i] = make_uint2(meta, prim);
     }
     // a closer hit on a mesh: the normal is left to shade_path, which rebuilds it from triangle `tri`
     static constexpr bool DEFER_NORMAL = true;
-    RT_DEV void hit_mesh(uint32_t slot, float t, uint32_t meta, uint32_t tri) const {
-        ((float*)&pa.hit_a[slot])[0] = t;
-        pa.hit_b[slot] = make_uint2(meta, tri);
+    RT_DEV void hit_mesh(uint32_t i, float t, uint32_t meta, uint32_t tri) const {
+        ((float*)&pa.hit_a[i])[0] = t;
+        pa.hit_b[i] = make_uint2(meta, tri);
     }
-    RT_DEV void emit_closest(uint32_t slot, bool got, const Visits& vis) {
-        if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
+    RT_DEV void emit_closest(uint32_t i, bool got, const Visits& vis) {
+        if (!got) pa.hit_b[i] = make_uint2(RT_MISS, RT_MISS);
         n_int += vis.n_int;
         n_tri += vis.n_tri;
     }
     RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
 };
 
+// launch-wide tuning of a render trace kernel: n_seg segments of seg_cap positions, counts in device memory
+RT_DEV TraceTune render_tune(const TuneBase& b, uint32_t n_total, uint32_t n_seg, uint32_t seg_cap) {
+    TraceTune t;
+    t.chunk = b.chunk ? b.chunk : (n_total >= (16u << 20) ? 128u : 64u);
+    t.refill_min = b.refill_min;
+    t.w_adv = b.w_adv;
+    t.w_node = b.w_node;
+    t.w_leaf = b.w_leaf;
+    t.n_seg = n_seg;
+    t.seg_len = seg_cap;
+    return t;
+}
+
 template <int COUNT>
-__global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, const uint32_t* queue, const uint32_t* counts, uint32_t first,
-                                                     uint32_t* work_counter, TuneBase base, uint32_t* overflow,
-                                                     uint32_t overflow_stride) {
+__global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, uint32_t first, TuneBase base, uint32_t* overflow,
+                                       uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t n = counts[0];
-    const TraceTune tune = make_tune(base, n, gridDim.x);
-    ExtendIO io{pa, queue, 0ull, 0ull, (first & 1u) != 0u, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
-    trace_loop<TRACE_CLOSEST, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                             lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    const uint32_t n = pa.cnt[CNT_TOT_ALIVE];
+    const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
+    ExtendIO io{pa, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
+    trace_loop<TRACE_CLOSEST, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
+                                                             lds_stack + threadIdx.x, overflow + gtid, overflow_stride,
+                                                             pa.cnt + CNT_ALIVE);
     if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
 }
 
 // The same kernel for scenes whose objects are meshes and planes (rtd::SceneFeatures): fewer registers, more waves.
-__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, const uint32_t* queue, const uint32_t* counts, uint32_t first,
-                                                 uint32_t* work_counter, TuneBase base, uint32_t* overflow,
+__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, uint32_t first, TuneBase base, uint32_t* overflow,
                                                  uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t n = counts[0];
-    const TraceTune tune = make_tune(base, n, gridDim.x);
-    ExtendIO io{pa, queue, 0ull, 0ull, (first & 1u) != 0u, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
-    trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                                  lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    const uint32_t n = pa.cnt[CNT_TOT_ALIVE];
+    const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
+    ExtendIO io{pa, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
+    trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
+        sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_ALIVE);
 }
 
 // ---------------------------------------------------------------- shadow-connect
 // The NEE term of an unoccluded shadow ray joins the path's radiance (path_integrator.rs:234-236).  Term and
 // radiance are requested together and the sum is stored either way (unchanged bits when p_light was 0): the
 // wave waits for one round trip here, not for two in a row.
-RT_DEV void add_pending_nee(const PathArrays& pa, uint32_t slot) {
-    const float4 c = pa.sh_c[slot];
-    const uint32_t id = pa.oid ? pa.oid[slot] : slot;  // uniform: dense region or the first one
+RT_DEV void add_pending_nee(const PathArrays& pa, uint32_t i, uint32_t id) {  // shadow record i of the path with original slot id
+    const float4 c = pa.sh_c[i];
     float4 r = pa.rad[id];
     const bool add = c.w != 0.0f;  // p_light > 0
     r.x = add ? r.x + c.x : r.x;
@@ -225,51 +259,47 @@ RT_DEV void add_pending_nee(const PathArrays& pa, uint32_t slot) {
     pa.rad[id] = r;
 }
 
-struct ShadowIO {  // rays come from the shadow queue; an unoccluded ray adds its pending NEE term
+struct ShadowIO {  // ray i = shadow record i; an unoccluded ray adds its pending NEE term
     PathArrays pa;
     unsigned long long n_int, n_tri;
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {
-        const uint32_t slot = pa.shadow_q[i];
-        float4 o4 = pa.ray_o[slot], d4 = pa.sh_d[slot];
+        float4 o4 = pa.sh_o[i], d4 = pa.sh_d[i];
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
-        return slot;
+        return i;
     }
     static constexpr bool DEFER_NORMAL = false;
     RT_DEV void hit(uint32_t, float, V3, uint32_t, uint32_t) const {}
     RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
-    RT_DEV void emit_any(uint32_t slot, bool occluded, const Visits& vis) {
-        if (!occluded) {
-            add_pending_nee(pa, slot);
-        }
+    RT_DEV void emit_any(uint32_t i, bool occluded, const Visits& vis) {
+        if (!occluded) add_pending_nee(pa, i, __float_as_uint(pa.sh_o[i].w));
         n_int += vis.n_int;
         n_tri += vis.n_tri;
     }
 };
 
-// path_integrator.rs:219: the shadow ray is tested over T_MIN..T_MAX, not up to the light.
+// path_integrator.rs:219: the shadow ray is tested over T_MIN..T_MAX, not up to the light.  pa.cnt is the counts block
+// k_publish wrote AFTER the bounce that produced the rays: its CNT_SHADOW half.
 template <int COUNT>
-__global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, const uint32_t* counts, uint32_t* work_counter,
-                                                     TuneBase base, uint32_t* overflow, uint32_t overflow_stride) {
+__global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, TuneBase base, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_ANY * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t n = counts[1];
-    const TraceTune tune = make_tune(base, n, gridDim.x);
+    const uint32_t n = pa.cnt[CNT_TOT_SHADOW];
+    const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
     ShadowIO io{pa, 0ull, 0ull};
-    trace_loop<TRACE_ANY, COUNT, RT_STACK_ANY, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                         lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    trace_loop<TRACE_ANY, COUNT, RT_STACK_ANY, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
+                                                         lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_SHADOW, NSEG);
     if (COUNT) add_visits(&pa.visit[2], io.n_int, io.n_tri);
 }
 
-__global__ RT_TRACE_ATTR_LEAN_ANY void k_shadow_lean(DScene sc, PathArrays pa, const uint32_t* counts, uint32_t* work_counter,
-                                                     TuneBase base, uint32_t* overflow, uint32_t overflow_stride) {
+__global__ RT_TRACE_ATTR_LEAN_ANY void k_shadow_lean(DScene sc, PathArrays pa, TuneBase base, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN_ANY * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t n = counts[1];
-    const TraceTune tune = make_tune(base, n, gridDim.x);
+    const uint32_t n = pa.cnt[CNT_TOT_SHADOW];
+    const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
     ShadowIO io{pa, 0ull, 0ull};
-    trace_loop<TRACE_ANY, false, RT_STACK_LEAN_ANY, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                              lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    trace_loop<TRACE_ANY, false, RT_STACK_LEAN_ANY, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
+        sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_SHADOW, NSEG);
 }
 
 // ---------------------------------------------------------------- shade
@@ -292,9 +322,17 @@ RT_DEV rt_light load_light_uniform(const rt_light* lights, uint32_t l) {
     return out;
 }
 
-// One iteration of the loop body of ray_colour for the path in `slot`.  Returns QF_* flags.
+// What an iteration leaves behind besides radiance: the state of the path's next ray (QF_ALIVE) and its shadow ray
+// (QF_SHADOW).  The caller decides where they go (k_shade: compacted into the next region; k_tail: in place).
+struct ShadeOut {
+    float4 o4, d4, b4;  // next ray: origin | medium bits, direction | prev_pdf, throughput | depth bits (o4 also when only QF_SHADOW: the vertex)
+    float4 sh_d, sh_c;  // shadow direction, pending NEE term | apply flag
+    uint32_t id;        // the path's original slot
+};
+
+// One iteration of the loop body of ray_colour for the path at position `slot`.  Returns QF_* flags.
 RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot,
-                           uint32_t bounce) {
+                           uint32_t bounce, ShadeOut& out) {
     // Everything the slot names is requested at once: nothing below depends on anything but `slot`, and a
     // wave that waits for each record in turn spends its time in memory round trips (4 waves per SIMD).
     float4 d4 = pa.ray_d[slot], o4, b4;
@@ -329,6 +367,7 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
 
     depth -= 1;  // `while depth > 0 { depth -= 1;` (:150-151)
     const uint32_t id = pa.oid ? pa.oid[slot] : slot;  // the path's original slot: pixel, sample, radiance record
+    out.id = id;
     uint32_t pixel, s_local;
     slot_pixel(rp, id, &pixel, &s_local);
     Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + s_local, bounce, 0u};
@@ -385,9 +424,9 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         } else {
             depth -= 1;  // u32, wraps at 0 exactly like the release-mode reference (:193)
             beta = beta * (transmittance * mi.f / mi.pdf);
-            pa.ray_o[slot] = make_float4(mi.origin.x, mi.origin.y, mi.origin.z, o4.w);
-            pa.ray_d[slot] = make_float4(mi.dir.x, mi.dir.y, mi.dir.z, prev_pdf);
-            pa.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(depth));
+            out.o4 = make_float4(mi.origin.x, mi.origin.y, mi.origin.z, o4.w);
+            out.d4 = make_float4(mi.dir.x, mi.dir.y, mi.dir.z, prev_pdf);
+            out.b4 = make_float4(beta.x, beta.y, beta.z, __uint_as_float(depth));
             return depth > 0 ? QF_ALIVE : 0;  // `continue`
         }
     }
@@ -424,8 +463,8 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         // run through it (frame 58.6 -> 53.9 ms, same bits).
         const bool useless = rp.skip_zero_nee && (!(p_light > 0.0f) || (add.x == 0.0f && add.y == 0.0f && add.z == 0.0f));
         if (!useless) {
-            pa.sh_d[slot] = make_float4(ls.direction.x, ls.direction.y, ls.direction.z, 0.0f);
-            pa.sh_c[slot] = make_float4(add.x, add.y, add.z, p_light > 0.0f ? 1.0f : 0.0f);
+            out.sh_d = make_float4(ls.direction.x, ls.direction.y, ls.direction.z, 0.0f);
+            out.sh_c = make_float4(add.x, add.y, add.z, p_light > 0.0f ? 1.0f : 0.0f);
             flags |= QF_SHADOW;
         } else {
             flags |= QF_SKIPPED;
@@ -444,45 +483,103 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
     // Russian roulette (:263-272)
     float q = 1.0f - max_elem(beta);
     const bool survives = !(rng.f32() < q);
-    // the vertex is the origin of the next ray AND of the pending shadow ray: written if either exists
-    if (survives || (flags & QF_SHADOW))
-        pa.ray_o[slot] = make_float4(interaction_point.x, interaction_point.y, interaction_point.z,
-                                     pack_medium(medium, bs.is_specular));
+    // the vertex is the origin of the next ray AND of the pending shadow ray
+    out.o4 = make_float4(interaction_point.x, interaction_point.y, interaction_point.z, pack_medium(medium, bs.is_specular));
     if (!survives) return flags;
     beta = div_assign(beta, 1.0f - q);
-    pa.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, prev_pdf);
-    pa.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(depth));
+    out.d4 = make_float4(nd.x, nd.y, nd.z, prev_pdf);
+    out.b4 = make_float4(beta.x, beta.y, beta.z, __uint_as_float(depth));
     if (depth > 0) flags |= QF_ALIVE;
     return flags;
 }
 
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa, RenderParams rp,
-                                                       const uint32_t* queue, const uint32_t* counts) {
+// Block b works on segment b % ns (consecutive blocks on different segments: see NSEG above), on the 256 positions
+// from (b / ns) * 256 of that segment.  After shading, the block's survivors and shadow rays are counted (ballots),
+// the block reserves room for both in its segment of the next region / of the shadow records with one atomic, and
+// every lane writes its records to its place: block offset + waves before + rank inside the wave's ballot.  Inside a
+// block the order of the paths is kept, between blocks it is the order the reservations arrive in -- close to the
+// launch order, so what was coherent stays so, and no bit of the image depends on it.
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa, RenderParams rp) {
     __shared__ uint32_t wave_cnt[3][SHADE_BLOCK / 64];
-    const uint32_t n = counts[0];
-    if (blockIdx.x * SHADE_BLOCK >= n) return;  // the grid is sized from an upper bound of n (uniform per block)
-    uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+    __shared__ uint32_t base[2];
+    const uint32_t seg = blockIdx.x % pa.ns, first = (blockIdx.x / pa.ns) * SHADE_BLOCK;
+    const uint32_t n = pa.cnt[CNT_ALIVE + seg];
+    if (first >= n) return;  // the grid is sized from an upper bound of the fullest segment (uniform per block)
+    const uint32_t local = first + threadIdx.x, seg0 = seg * pa.seg_stride;
+    const uint32_t oseg = seg / (pa.ns / pa.ns_out), oseg0 = oseg * pa.out_stride;  // where this segment's survivors go
     uint32_t flags = 0;
-    if (i < n) {
-        // the first bounce's queue is the identity (k_generate): no look-up
-        flags = shade_path(sc, pa, rp, rp.identity_queue ? i : queue[i], rp.bounce);
-        pa.qflags[i] = flags;
-    }
-    // block totals for the compaction scan (wave ballots)
-    unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
-    unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
-    unsigned long long skipped = __ballot((flags & QF_SKIPPED) != 0);
-    uint32_t wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
+    ShadeOut out;
+    if (local < n) flags = shade_path(sc, pa, rp, seg0 + local, rp.bounce, out);
+    const unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
+    const unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
+    const unsigned long long skipped = __ballot((flags & QF_SKIPPED) != 0);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
         wave_cnt[0][wave] = (uint32_t)__popcll(alive);
         wave_cnt[1][wave] = (uint32_t)__popcll(shadow);
         wave_cnt[2][wave] = (uint32_t)__popcll(skipped);
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
-        uint32_t s = 0;
-        for (int w = 0; w < SHADE_BLOCK / 64; ++w) s += wave_cnt[threadIdx.x][w];
-        pa.block_cnt[threadIdx.x * pa.max_blocks + blockIdx.x] = s;
+    if (threadIdx.x == 0) {
+        uint32_t t[3] = {0, 0, 0};
+        for (int w = 0; w < SHADE_BLOCK / 64; ++w)
+            for (int q = 0; q < 3; ++q) t[q] += wave_cnt[q][w];
+        unsigned long long r = 0ull;
+        if (t[0] | t[1]) r = atomicAdd(&pa.acc[oseg * ACC_STRIDE], (unsigned long long)t[0] | ((unsigned long long)t[1] << 32));
+        base[0] = (uint32_t)r;
+        base[1] = (uint32_t)(r >> 32);
+        if (t[2]) atomicAdd(pa.acc_skipped, t[2]);
+    }
+    __syncthreads();
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (flags & QF_ALIVE) {
+        uint32_t pos = oseg0 + base[0] + (uint32_t)__popcll(alive & below);
+        for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[0][w];
+        pa.nray_o[pos] = out.o4;
+        pa.nray_d[pos] = out.d4;
+        pa.nbeta[pos] = out.b4;
+        pa.noid[pos] = out.id;
+    }
+    if (flags & QF_SHADOW) {
+        uint32_t pos = oseg0 + base[1] + (uint32_t)__popcll(shadow & below);
+        for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[1][w];
+        pa.sh_o[pos] = make_float4(out.o4.x, out.o4.y, out.o4.z, __uint_as_float(out.id));
+        pa.sh_d[pos] = out.sh_d;
+        pa.sh_c[pos] = out.sh_c;
+    }
+}
+
+// One wave after every k_shade: the reservations become the counts of the next bounce (CNT_* layout) -- for the kernels
+// that follow in the stream and, through pinned memory, for the host (totals, fullest segment) -- and the accumulators
+// and the work counters of the trace launches start again at zero.
+__global__ __launch_bounds__(64) void k_publish(PathArrays pa, uint32_t* cnt_out, uint32_t* counts_host) {
+    const uint32_t s = threadIdx.x;  // NSEG == 64 == one wave
+    const unsigned long long r = pa.acc[s * ACC_STRIDE];
+    pa.acc[s * ACC_STRIDE] = 0ull;
+    const uint32_t a = (uint32_t)r, sh = (uint32_t)(r >> 32);  // zero beyond ns_out: nobody reserved there
+    cnt_out[CNT_ALIVE + s] = a;
+    cnt_out[CNT_SHADOW + s] = sh;
+    if (s < pa.ns_out) {
+        cnt_out[CNT_MIXED + s] = sh;
+        cnt_out[CNT_MIXED + pa.ns_out + s] = a;
+    }
+    uint32_t ta = a, ts = sh, ma = a;
+    for (int off = 32; off > 0; off >>= 1) {
+        ta += __shfl_down(ta, off);
+        ts += __shfl_down(ts, off);
+        ma = max(ma, (uint32_t)__shfl_down(ma, off));
+    }
+    for (uint32_t i = s; i < WORK_BUF_U32; i += 64u) pa.work[i] = 0u;
+    if (s == 0) {
+        const uint32_t sk = *pa.acc_skipped;
+        *pa.acc_skipped = 0u;
+        cnt_out[CNT_TOT_ALIVE] = ta;
+        cnt_out[CNT_TOT_SHADOW] = ts;
+        counts_host[0] = ta;  // paths alive after this bounce
+        counts_host[1] = ts;  // its shadow rays
+        counts_host[2] = sk;  // shadow rays not needed
+        counts_host[3] = ma;  // paths in the fullest segment
+        __threadfence_system();
     }
 }
 
@@ -499,40 +596,38 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
 // each iteration costs more -- 219 000 paths took 4.0 ms here against 4.3 ms as five wavefront rounds
 // (profiles/r01/tuning.md), hence the low threshold.
 struct TailIO {
-    PathArrays pa;
-    const uint32_t* queue;
+    PathArrays pa;      // the region the paths are in; their state is updated IN PLACE (nothing is compacted here)
     const DScene* sc;
     const RenderParams* rp;
     uint32_t n_closest, n_shadow, n_skipped, iters, max_iters;  // per lane
     unsigned long long n_int, n_tri;                   // closest-hit visits (COUNT)
     unsigned long long n_int_sh, n_tri_sh;             // shadow visits (COUNT)
     bool alive_after;                                  // the path goes on after its pending shadow ray
-    bool identity;                                     // queue position = slot
+    uint32_t id;                                       // original slot of the lane's path
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) {
-        const uint32_t slot = identity ? i : queue[i];
-        float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
+        float4 o4 = pa.ray_o[i], d4 = pa.ray_d[i];
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
         n_closest += 1;
         iters = 1;
         if (iters > max_iters) max_iters = iters;
-        return slot;
+        return i;
     }
     static constexpr bool DEFER_NORMAL = true;
-    RT_DEV void hit_mesh(uint32_t slot, float t, uint32_t meta, uint32_t tri) const {
-        ((float*)&pa.hit_a[slot])[0] = t;
-        pa.hit_b[slot] = make_uint2(meta, tri);
+    RT_DEV void hit_mesh(uint32_t i, float t, uint32_t meta, uint32_t tri) const {
+        ((float*)&pa.hit_a[i])[0] = t;
+        pa.hit_b[i] = make_uint2(meta, tri);
     }
     static constexpr bool CONTINUES = true;  // next() carries the lane on to the path's shadow ray / next bounce
     RT_DEV bool first_is_any(uint32_t) const { return false; }
-    RT_DEV void hit(uint32_t slot, float t, V3 n, uint32_t meta, uint32_t prim) const {
-        pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
-        pa.hit_b[slot] = make_uint2(meta, prim);
+    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
+        pa.hit_a[i] = make_float4(t, n.x, n.y, n.z);
+        pa.hit_b[i] = make_uint2(meta, prim);
     }
     RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
     RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
-    RT_DEV bool next_bounce(uint32_t slot, V3* o, V3* d, bool* any) {
-        float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot];
+    RT_DEV bool next_bounce(uint32_t i, V3* o, V3* d, bool* any) {
+        float4 o4 = pa.ray_o[i], d4 = pa.ray_d[i];
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
         *any = false;
@@ -541,18 +636,25 @@ struct TailIO {
         if (iters > max_iters) max_iters = iters;
         return true;
     }
-    RT_DEV bool next(uint32_t slot, bool was_any, bool got, bool occluded, const Visits& vis, V3* o, V3* d, bool* any) {
+    RT_DEV bool next(uint32_t i, bool was_any, bool got, bool occluded, const Visits& vis, V3* o, V3* d, bool* any) {
         if (!was_any) {
             n_int += vis.n_int;
             n_tri += vis.n_tri;
-            if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
-            const uint32_t flags = shade_path(*sc, pa, *rp, slot, rp->bounce + iters - 1u);
+            if (!got) pa.hit_b[i] = make_uint2(RT_MISS, RT_MISS);
+            ShadeOut out;
+            const uint32_t flags = shade_path(*sc, pa, *rp, i, rp->bounce + iters - 1u, out);
+            id = out.id;
             alive_after = (flags & QF_ALIVE) != 0;
             if (flags & QF_SKIPPED) n_skipped += 1;
+            if (flags & QF_ALIVE) {
+                pa.ray_o[i] = out.o4;
+                pa.ray_d[i] = out.d4;
+                pa.beta[i] = out.b4;
+            }
             if (flags & QF_SHADOW) {
-                float4 o4 = pa.ray_o[slot], d4 = pa.sh_d[slot];
-                *o = v3(o4.x, o4.y, o4.z);
-                *d = v3(d4.x, d4.y, d4.z);
+                pa.sh_c[i] = out.sh_c;
+                *o = v3(out.o4.x, out.o4.y, out.o4.z);
+                *d = v3(out.sh_d.x, out.sh_d.y, out.sh_d.z);
                 *any = true;
                 n_shadow += 1;
                 return true;
@@ -560,11 +662,9 @@ struct TailIO {
         } else {
             n_int_sh += vis.n_int;
             n_tri_sh += vis.n_tri;
-            if (!occluded) {
-                add_pending_nee(pa, slot);
-            }
+            if (!occluded) add_pending_nee(pa, i, id);
         }
-        return alive_after ? next_bounce(slot, o, d, any) : false;
+        return alive_after ? next_bounce(i, o, d, any) : false;
     }
 };
 
@@ -575,16 +675,15 @@ RT_DEV unsigned long long wave_sum_u64(unsigned long long v) {
 
 // pa.tail[0..7]: closest rays, shadow rays, n_int, n_tri (closest), n_int, n_tri (shadow), max iterations, shadow rays not needed
 template <int COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, RenderParams rp, const uint32_t* queue,
-                                                   const uint32_t* counts, uint32_t* work_counter, TuneBase base,
-                                                   uint32_t* overflow, uint32_t overflow_stride) {
+__global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, RenderParams rp, TuneBase base, uint32_t* overflow,
+                                                   uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t n = counts[0];
-    const TraceTune tune = make_tune(base, n, gridDim.x);
-    TailIO io{pa, queue, &sc, &rp, 0u, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false, rp.identity_queue != 0u};
-    trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    const uint32_t n = pa.cnt[CNT_TOT_ALIVE];
+    const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
+    TailIO io{pa, &sc, &rp, 0u, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false, 0u};
+    trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
+                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_ALIVE);
     unsigned long long v[6] = {io.n_closest, io.n_shadow, io.n_int, io.n_tri, io.n_int_sh, io.n_tri_sh};
     uint32_t mx = io.max_iters;
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
@@ -601,214 +700,83 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, Ren
 // ---------------------------------------------------------------- mixed (every bounce but the largest)
 // A traversal launch ends with a drain -- waves finishing their last, longest rays (~0.35 ms) while the
 // rest of the chip idles -- and a bounce has two launches: the shadow rays of bounce k, then the rays of
-// bounce k+1.  Neither depends on the other (one adds to the radiance, the other writes hit records; both
-// only read the vertex in ray_o), so up to RT_MIX_PATHS rays (default 128 Mi; per ray the mixed loop costs
-// a little more than the dedicated kernels, per launch it saves one drain: 1080p frame 68.4 / 66.1 / 68.4 ms
-// at 4 Mi / 64-128 Mi / 256 Mi) they share ONE launch: items [0, n_shadow) are the shadow
-// queue, items [n_shadow, n_shadow + n_next) the live-path queue.  k_shade of bounce k+1 still runs after
-// both, so the order of additions into a path's radiance is unchanged.
+// bounce k+1.  Neither depends on the other (one adds to the radiance, the other writes hit records), so up to
+// RT_MIX_PATHS rays (default 128 Mi; per ray the mixed loop costs a little more than the dedicated kernels, per launch
+// it saves one drain: 1080p frame 68.4 / 66.1 / 68.4 ms at 4 Mi / 64-128 Mi / 256 Mi) they share ONE launch of 2 NSEG
+// segments: segment s < NSEG is segment s of the shadow records, segment NSEG + s is segment s of the region the
+// survivors went to.  k_shade of bounce k+1 still runs after both, so the order of additions into a path's radiance is
+// unchanged.  `pa` is the view of bounce k+1 (its region, the counts k_publish wrote after bounce k).
 struct MixedIO {
-    PathArrays ps;          // region the shadow rays of this bounce live in
-    PathArrays pa;          // region of the next bounce's rays (the same one unless the compaction moved the paths)
-    const uint32_t* queue;  // live paths of the NEXT bounce
-    uint32_t n_shadow;
-    bool identity;          // queue position = slot in `pa`
+    PathArrays pa;
+    uint32_t n_shadow_items;  // NSEG * seg_cap: items below it are shadow records, item i at or above it is position i - n_shadow_items
     unsigned long long n_int, n_tri, n_int_sh, n_tri_sh;
     static constexpr bool CONTINUES = false;  // a finished ray is finished: the lane takes a new one
-    RT_DEV bool first_is_any(uint32_t i) const { return i < n_shadow; }
-    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {
-        const bool sh = i < n_shadow;
-        uint32_t slot;
+    RT_DEV bool first_is_any(uint32_t i) const { return i < n_shadow_items; }
+    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // the tag is the item
+        const bool sh = i < n_shadow_items;
+        const uint32_t k = sh ? i : i - n_shadow_items;
         float4 o4, d4;
         if (sh) {
-            slot = ps.shadow_q[i];
-            o4 = ps.ray_o[slot];
-            d4 = ps.sh_d[slot];
+            o4 = pa.sh_o[k];
+            d4 = pa.sh_d[k];
         } else {
-            slot = identity ? i - n_shadow : queue[i - n_shadow];
-            o4 = pa.ray_o[slot];
-            d4 = pa.ray_d[slot];
+            o4 = pa.ray_o[k];
+            d4 = pa.ray_d[k];
         }
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
-        return slot;
+        return i;
     }
     static constexpr bool DEFER_NORMAL = true;
-    RT_DEV void hit_mesh(uint32_t slot, float t, uint32_t meta, uint32_t tri) const {
-        ((float*)&pa.hit_a[slot])[0] = t;
-        pa.hit_b[slot] = make_uint2(meta, tri);
+    RT_DEV void hit_mesh(uint32_t i, float t, uint32_t meta, uint32_t tri) const {
+        const uint32_t k = i - n_shadow_items;
+        ((float*)&pa.hit_a[k])[0] = t;
+        pa.hit_b[k] = make_uint2(meta, tri);
     }
-    RT_DEV void hit(uint32_t slot, float t, V3 n, uint32_t meta, uint32_t prim) const {
-        pa.hit_a[slot] = make_float4(t, n.x, n.y, n.z);
-        pa.hit_b[slot] = make_uint2(meta, prim);
+    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
+        const uint32_t k = i - n_shadow_items;
+        pa.hit_a[k] = make_float4(t, n.x, n.y, n.z);
+        pa.hit_b[k] = make_uint2(meta, prim);
     }
     RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
     RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
-    RT_DEV bool next(uint32_t slot, bool was_any, bool got, bool occluded, const Visits& vis, V3*, V3*, bool*) {
+    RT_DEV bool next(uint32_t i, bool was_any, bool got, bool occluded, const Visits& vis, V3*, V3*, bool*) {
         if (was_any) {
             n_int_sh += vis.n_int;
             n_tri_sh += vis.n_tri;
-            if (!occluded) {
-                add_pending_nee(ps, slot);
-            }
+            if (!occluded) add_pending_nee(pa, i, __float_as_uint(pa.sh_o[i].w));
         } else {
             n_int += vis.n_int;
             n_tri += vis.n_tri;
-            if (!got) pa.hit_b[slot] = make_uint2(RT_MISS, RT_MISS);
+            if (!got) pa.hit_b[i - n_shadow_items] = make_uint2(RT_MISS, RT_MISS);
         }
         return false;
     }
 };
 
 template <int COUNT>
-__global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays ps, PathArrays pa, const uint32_t* queue, const uint32_t* counts,
-                                      uint32_t identity, uint32_t* work_counter, TuneBase base, uint32_t* overflow,
-                                      uint32_t overflow_stride) {
+__global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, TuneBase base, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t n_shadow = counts[1], n = n_shadow + counts[0];  // shadow rays of this bounce, then the rays of the next
-    const TraceTune tune = make_tune(base, n, gridDim.x);
-    MixedIO io{ps, pa, queue, n_shadow, identity != 0u, 0ull, 0ull, 0ull, 0ull};
-    trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, work_counter, tune, T_MIN, __builtin_inff(),
-                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride);
+    const uint32_t n = pa.cnt[CNT_TOT_SHADOW] + pa.cnt[CNT_TOT_ALIVE];  // shadow rays of this bounce, then the rays of the next
+    const TraceTune tune = render_tune(base, n, 2u * pa.ns, pa.seg_stride);
+    MixedIO io{pa, pa.n_positions, 0ull, 0ull, 0ull, 0ull};
+    trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
+                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_MIXED);
     if (COUNT) {  // accounted with the tail kernel's share: rays traced outside k_extend / k_shadow
         add_visits(&pa.tail[2], io.n_int, io.n_tri);
         add_visits(&pa.tail[4], io.n_int_sh, io.n_tri_sh);
     }
 }
 
-__global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays ps, PathArrays pa, const uint32_t* queue, const uint32_t* counts,
-                                                uint32_t identity, uint32_t* work_counter, TuneBase base, uint32_t* overflow,
-                                                uint32_t overflow_stride) {
+__global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays pa, TuneBase base, uint32_t* overflow, uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t n_shadow = counts[1], n = n_shadow + counts[0];
-    const TraceTune tune = make_tune(base, n, gridDim.x);
-    MixedIO io{ps, pa, queue, n_shadow, identity != 0u, 0ull, 0ull, 0ull, 0ull};
-    trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(sc, io, n, work_counter, tune, T_MIN,
-                                                                         __builtin_inff(), lds_stack + threadIdx.x,
-                                                                         overflow + gtid, overflow_stride);
-}
-
-// ---------------------------------------------------------------- compact
-// Exclusive scan of the per-block totals in two levels, both queues (alive, shadow) at once:
-//   k_compact_scan_groups: one workgroup per 1024 consecutive shade blocks -- coalesced read, wave
-//       shuffle scan, LDS scan of the 16 wave totals; writes offsets local to the group + the group total
-//   k_compact_scan_top:    one workgroup scans the group totals (<= 8192 groups: 2^31 slots / 256 / 1024)
-// The scatter adds group offset + local offset.  (The first version scanned everything in ONE
-// workgroup with a serial strip per thread: 2.6 ms for the 518 400 blocks of a 64-spp 1080p batch.)
-constexpr uint32_t SCAN_GROUP = 1024;
-
-RT_DEV uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wave_sum /*[16]*/, uint32_t* total) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t x = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t y = __shfl_up(x, off);
-        if (lane >= (uint32_t)off) x += y;
-    }
-    if (lane == 63) wave_sum[wave] = x;
-    __syncthreads();
-    if (wave == 0) {
-        uint32_t w = lane < 16 ? wave_sum[lane] : 0u;
-        uint32_t t = w;
-        for (int off = 1; off < 16; off <<= 1) {
-            uint32_t y = __shfl_up(t, off);
-            if (lane >= (uint32_t)off) t += y;
-        }
-        if (lane < 16) wave_sum[lane] = t - w;  // exclusive over waves
-        if (lane == 15) *total = t;
-    }
-    __syncthreads();
-    return x - v + wave_sum[wave];
-}
-
-__global__ __launch_bounds__(1024) void k_compact_scan_groups(PathArrays pa, const uint32_t* counts) {
-    __shared__ uint32_t wave_sum[3][16];
-    __shared__ uint32_t total[3];
-    const uint32_t n = counts[0];
-    const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
-    if (blockIdx.x * SCAN_GROUP >= n_blocks) return;  // grid sized from an upper bound of n
-    const uint32_t b = blockIdx.x * SCAN_GROUP + threadIdx.x;
-    for (int q = 0; q < 3; ++q) {  // alive, shadow, skipped (a total only: nothing is scattered for it)
-        const uint32_t v = b < n_blocks ? pa.block_cnt[q * pa.max_blocks + b] : 0u;
-        const uint32_t e = block_excl_scan_1024(v, wave_sum[q], &total[q]);
-        if (q < 2 && b < n_blocks) pa.block_off[q * pa.max_blocks + b] = e;
-    }
-    if (threadIdx.x < 3) pa.group_tot[threadIdx.x * pa.max_groups + blockIdx.x] = total[threadIdx.x];
-}
-
-// One workgroup: scans the group totals, publishes the counts of the next bounce -- to device memory for the kernels
-// that follow in the stream, and to pinned host memory for the host, which reads them a bounce later -- and zeroes
-// the work counters of the trace launches that follow.
-__global__ __launch_bounds__(1024) void k_compact_scan_top(PathArrays pa, const uint32_t* counts, uint32_t* counts_out,
-                                                           uint32_t* counts_host) {
-    __shared__ uint32_t wave_sum[3][16];
-    __shared__ uint32_t total[3];
-    const uint32_t n = counts[0];
-    const uint32_t n_blocks = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
-    const uint32_t n_groups = (n_blocks + SCAN_GROUP - 1) / SCAN_GROUP;
-    const uint32_t per = (n_groups + 1023u) / 1024u;  // <= 8
-    const uint32_t begin = threadIdx.x * per, end = min(begin + per, n_groups);
-    for (int q = 0; q < 3; ++q) {
-        uint32_t s = 0;
-        for (uint32_t g = begin; g < end; ++g) s += pa.group_tot[q * pa.max_groups + g];
-        uint32_t run = block_excl_scan_1024(s, wave_sum[q], &total[q]);
-        for (uint32_t g = begin; q < 2 && g < end; ++g) {
-            const uint32_t c = pa.group_tot[q * pa.max_groups + g];
-            pa.group_off[q * pa.max_groups + g] = run;
-            run += c;
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < 2u * WORK_U32; i += 1024u) pa.work[i] = 0u;
-    if (threadIdx.x < 3) {
-        counts_out[threadIdx.x] = total[threadIdx.x];  // [0] paths alive after this bounce, [1] its shadow rays, [2] shadow rays not needed
-        counts_host[threadIdx.x] = total[threadIdx.x];
-        __threadfence_system();
-    }
-}
-
-// Stable scatter: position = block offset + waves before + rank inside the wave ballot.
-// move != 0: a MOVING compaction -- the surviving paths' state (origin, direction, throughput and their w lanes) goes
-// to slot `position` of the dense region `dst` together with the path's original slot, and the next bounce's queue is
-// the identity.  Late bounces keep a fifth of the slots alive or less: every 16-byte record a kernel touched pulled a
-// 64-byte sector for it (k_shade: 106 ps per path at the third bounce against 38 ps at the second, profiles/r02).
-__global__ __launch_bounds__(SHADE_BLOCK) void k_compact_scatter(PathArrays pa, const uint32_t* queue, uint32_t* next_queue,
-                                                                 const uint32_t* counts, uint32_t identity, PathArrays dst,
-                                                                 uint32_t move) {
-    __shared__ uint32_t wave_cnt[2][SHADE_BLOCK / 64];
-    const uint32_t n = counts[0];
-    if (blockIdx.x * SHADE_BLOCK >= n) return;
-    uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
-    uint32_t flags = i < n ? pa.qflags[i] : 0u;
-    uint32_t slot = i < n ? (identity ? i : queue[i]) : 0u;  // the first bounce's queue is the identity: no look-up
-    unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
-    unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
-    uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        wave_cnt[0][wave] = (uint32_t)__popcll(alive);
-        wave_cnt[1][wave] = (uint32_t)__popcll(shadow);
-    }
-    __syncthreads();
-    unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    if (flags & QF_ALIVE) {
-        uint32_t pos = pa.group_off[blockIdx.x / SCAN_GROUP] + pa.block_off[blockIdx.x];
-        for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[0][w];
-        pos += (uint32_t)__popcll(alive & below);
-        if (move) {  // uniform
-            const float4 o4 = pa.ray_o[slot], d4 = pa.ray_d[slot], b4 = pa.beta[slot];
-            dst.ray_o[pos] = o4;
-            dst.ray_d[pos] = d4;
-            dst.beta[pos] = b4;
-            dst.oid[pos] = pa.oid ? pa.oid[slot] : slot;
-        } else {
-            next_queue[pos] = slot;
-        }
-    }
-    if (flags & QF_SHADOW) {
-        uint32_t pos = pa.group_off[pa.max_groups + blockIdx.x / SCAN_GROUP] + pa.block_off[pa.max_blocks + blockIdx.x];
-        for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[1][w];
-        pa.shadow_q[pos + (uint32_t)__popcll(shadow & below)] = slot;
-    }
+    const uint32_t n = pa.cnt[CNT_TOT_SHADOW] + pa.cnt[CNT_TOT_ALIVE];
+    const TraceTune tune = render_tune(base, n, 2u * pa.ns, pa.seg_stride);
+    MixedIO io{pa, pa.n_positions, 0ull, 0ull, 0ull, 0ull};
+    trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
+        sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_MIXED);
 }
 
 // ---------------------------------------------------------------- resolve
@@ -921,20 +889,23 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     // ---- batch size: samples in flight at once.  Every wavefront iteration ends in a tail of
     // half-empty waves and a host round trip, so the batch is made as large as memory allows
     // (measured at 1080p/32 spp: 8 Mi paths 145 ms, 64 Mi paths 71 ms): by default up to 40 % of
-    // the free HBM, ~212 B per path slot (148 B + two dense regions of a quarter of the slots, 128 B each).
+    // the free HBM, 192 B per path slot (two regions of 52 B, hit 24 B, shadow record 48 B, radiance 16 B).
     uint64_t max_paths = ctx->max_paths_in_flight;
     if (max_paths == 0) {
         size_t free_b = 0, total_b = 0;
         RT_HIP(hipMemGetInfo(&free_b, &total_b));
         free_b += ctx->path_state.bytes;  // our own previous allocation is reusable
-        max_paths = (uint64_t)((double)free_b * 0.4 / 212.0);
+        max_paths = (uint64_t)((double)free_b * 0.4 / 192.0);
         if (max_paths < ((uint64_t)1 << 20)) max_paths = (uint64_t)1 << 20;
     }
     uint32_t s_batch = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
     if (s_batch > spp_count) s_batch = spp_count ? spp_count : 1;
-    while ((uint64_t)s_batch * npix > 0x7FFFFFFFull) --s_batch;
+    constexpr uint64_t MAX_BATCH = 0x7F000000ull;  // 2 NSEG segments of a mixed launch stay below 2^32 items
+    while ((uint64_t)s_batch * npix > MAX_BATCH) --s_batch;
     const uint64_t P = (uint64_t)s_batch * npix;
-    const uint32_t max_blocks = (uint32_t)((P + SHADE_BLOCK - 1) / SHADE_BLOCK);
+    // positions: NSEG segments of seg_cap (a multiple of the shade block) each
+    const uint32_t seg_cap = (uint32_t)(((P + NSEG - 1) / NSEG + SHADE_BLOCK - 1) / SHADE_BLOCK * SHADE_BLOCK);
+    const uint64_t Ppos = (uint64_t)seg_cap * NSEG;  // >= P
 
     // ---- carve the path state out of one allocation
     size_t off = 0;
@@ -943,55 +914,63 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    const uint32_t max_groups = max_blocks / SCAN_GROUP + 1;
-    // Regions: 0 = one slot per (sample, pixel) of the batch; 1 and 2 = dense regions of a quarter of the slots, the
-    // targets of the moving compaction (ping-pong).  rad, the scan scratch, counts and work counters are shared.
-    const uint64_t Rcap = std::max<uint64_t>(P / 4, 1);
     struct RegionOff {
-        size_t ray_o, ray_d, beta, hit_a, hit_b, sh_d, sh_c, q0, q1, sq, qf, oid;
-    } ro[3];
-    for (int r = 0; r < 3; ++r) {
-        const uint64_t cap = r == 0 ? P : Rcap;
-        ro[r].ray_o = carve(cap * 16), ro[r].ray_d = carve(cap * 16), ro[r].beta = carve(cap * 16), ro[r].hit_a = carve(cap * 16);
-        ro[r].hit_b = carve(cap * 8), ro[r].sh_d = carve(cap * 16), ro[r].sh_c = carve(cap * 16), ro[r].q0 = carve(cap * 4);
-        ro[r].q1 = carve(cap * 4), ro[r].sq = carve(cap * 4), ro[r].qf = carve(cap * 4), ro[r].oid = r == 0 ? 0 : carve(cap * 4);
-    }
-    size_t o_rad = carve(P * 16), o_bc = carve((size_t)max_blocks * 12), o_bo = carve((size_t)max_blocks * 8),
-           o_gt = carve((size_t)max_groups * 12), o_go = carve((size_t)max_groups * 8), o_cnt = carve(256), o_vis = carve(256),
-           o_tail = carve(256), o_work = carve(2 * rtd::WORK_U32 * 4);
+        size_t ray_o, ray_d, beta, oid;
+    } ro[2];
+    for (int r = 0; r < 2; ++r)
+        ro[r].ray_o = carve(Ppos * 16), ro[r].ray_d = carve(Ppos * 16), ro[r].beta = carve(Ppos * 16), ro[r].oid = carve(Ppos * 4);
+    const size_t o_hit_a = carve(Ppos * 16), o_hit_b = carve(Ppos * 8), o_sh_o = carve(Ppos * 16), o_sh_d = carve(Ppos * 16),
+                 o_sh_c = carve(Ppos * 16), o_rad = carve(P * 16);
+    // small state, zeroed together at the start of every batch: accumulators, skipped total, work counters
+    const size_t o_acc = carve((size_t)NSEG * ACC_STRIDE * 8), o_skip = carve(256), o_work = carve(rtd::WORK_BUF_U32 * 4);
+    const size_t zero_bytes = off - o_acc;
+    const size_t o_cnt = carve(2 * CNT_U32 * 4), o_vis = carve(256), o_tail = carve(256);
     int rc = ctx->path_state.ensure(off);
     if (rc != RT_OK) return rc;
     if ((rc = rt_ctx_ensure_readback(ctx)) != RT_OK) return rc;
     char* base = (char*)ctx->path_state.p;
-    PathArrays reg[3];
-    for (int r = 0; r < 3; ++r) {
-        PathArrays& q = reg[r];
-        q.ray_o = (float4*)(base + ro[r].ray_o);
-        q.ray_d = (float4*)(base + ro[r].ray_d);
-        q.beta = (float4*)(base + ro[r].beta);
+    uint32_t* const counts = (uint32_t*)(base + o_cnt);
+    // the arrays bounce k works on: its paths in region k & 1, the survivors go to the other one
+    // segments per bounce (see NSEG above): what a launch of that many rays wants; never growing over the bounces.
+    // ns_of[k + 1] has to be known when bounce k is shaded, i.e. from bounds the host has then.
+    std::vector<uint32_t> ns_of;
+    auto segments_for = [](uint64_t n) {
+        uint32_t ns = 1;
+        while (ns < NSEG && (uint64_t)ns * 2u * 131072u <= n) ns *= 2;
+        return ns;
+    };
+    auto view = [&](size_t k) {
+        PathArrays q;
+        const RegionOff &in = ro[k & 1], &out = ro[(k + 1) & 1];
+        q.ray_o = (float4*)(base + in.ray_o);
+        q.ray_d = (float4*)(base + in.ray_d);
+        q.beta = (float4*)(base + in.beta);
+        q.oid = k == 0 ? nullptr : (uint32_t*)(base + in.oid);  // first bounce: position = slot
+        q.nray_o = (float4*)(base + out.ray_o);
+        q.nray_d = (float4*)(base + out.ray_d);
+        q.nbeta = (float4*)(base + out.beta);
+        q.noid = (uint32_t*)(base + out.oid);
         q.rad = (float4*)(base + o_rad);
-        q.oid = r == 0 ? nullptr : (uint32_t*)(base + ro[r].oid);
-        q.hit_a = (float4*)(base + ro[r].hit_a);
-        q.hit_b = (uint2*)(base + ro[r].hit_b);
-        q.sh_d = (float4*)(base + ro[r].sh_d);
-        q.sh_c = (float4*)(base + ro[r].sh_c);
-        q.queue[0] = (uint32_t*)(base + ro[r].q0);
-        q.queue[1] = (uint32_t*)(base + ro[r].q1);
-        q.shadow_q = (uint32_t*)(base + ro[r].sq);
-        q.qflags = (uint32_t*)(base + ro[r].qf);
-        q.block_cnt = (uint32_t*)(base + o_bc);
-        q.block_off = (uint32_t*)(base + o_bo);
-        q.group_tot = (uint32_t*)(base + o_gt);
-        q.group_off = (uint32_t*)(base + o_go);
-        q.counts = (uint32_t*)(base + o_cnt);
-        q.counts_host = ctx->rb_host;
-        q.max_blocks = max_blocks;
-        q.max_groups = max_groups;
+        q.hit_a = (float4*)(base + o_hit_a);
+        q.hit_b = (uint2*)(base + o_hit_b);
+        q.sh_o = (float4*)(base + o_sh_o);
+        q.sh_d = (float4*)(base + o_sh_d);
+        q.sh_c = (float4*)(base + o_sh_c);
+        q.cnt = counts + CNT_U32 * (k & 1);
+        q.acc = (unsigned long long*)(base + o_acc);
+        q.acc_skipped = (uint32_t*)(base + o_skip);
+        q.n_positions = (uint32_t)Ppos;
+        q.ns = ns_of[k];
+        q.seg_stride = seg_cap * (NSEG / q.ns);
+        q.ns_out = ns_of[k + 1];
+        q.out_stride = seg_cap * (NSEG / q.ns_out);
         q.work = (uint32_t*)(base + o_work);
         q.visit = (unsigned long long*)(base + o_vis);
         q.tail = (unsigned long long*)(base + o_tail);
-    }
-    const PathArrays& pa = reg[0];  // what is not per region: rad, counts, work, visit, tail
+        return q;
+    };
+    ns_of.assign(2, NSEG);
+    const PathArrays pa = view(0);  // what does not depend on the bounce: rad, work, visit, tail
     RT_HIP(hipMemsetAsync(pa.visit, 0, 256, stream));
     RT_HIP(hipMemsetAsync(pa.tail, 0, 256, stream));
 
@@ -1012,13 +991,13 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     // visit counters: the reference's visits (equal to the oracle's) or the fetches the timed kernels perform
     const int count = (flags & RT_RENDER_COUNT_VISITS) ? rtd::COUNT_REFERENCE : (flags & RT_RENDER_COUNT_FETCHES) ? rtd::COUNT_FETCHES : rtd::COUNT_NONE;
     const bool use_tail = (flags & RT_RENDER_NO_TAIL) == 0;
-    // scenes without analytic sphere / triangle objects (meshes, planes, transforms) take the lean kernels
     static const uint64_t mix_paths = [] {  // RT_MIX_PATHS: rays (shadow + next bounce) up to which they share a launch
         const char* e = getenv("RT_MIX_PATHS");
         return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)134217728;
     }();
     const bool use_mix = use_tail && mix_paths > 0;
     uint64_t mixed_closest = 0, mixed_shadow = 0;
+    // scenes without analytic sphere / triangle objects (meshes, planes, transforms) take the lean kernels
     const bool lean = rt_scene_is_lean(ctx) && getenv("RT_NO_LEAN") == nullptr;
     static const uint32_t tail_paths = [] {  // RT_TAIL_PATHS overrides the switch-over point (experiments)
         const char* e = getenv("RT_TAIL_PATHS");
@@ -1028,13 +1007,12 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         const char* e = getenv("RT_ASYNC_BELOW");  // without waiting for their exact counts (0: always wait)
         return e ? (uint32_t)strtoul(e, nullptr, 10) : (16u << 20);
     }();
-    const bool use_move = getenv("RT_NO_MOVE") == nullptr;  // moving compaction (k_compact_scatter)
     const bool timing = (flags & RT_RENDER_TIME_STAGES) != 0;
     // HIP events on the library's stream around every launch of a stage, summed per stage after the frame's last
     // synchronisation (the host runs ahead of the device, so a span cannot be read back where it is recorded).
     // k_extend (stage 1, the kernel the roofline figure is about) and the mixed / tail launches (stage 5) are always
     // timed; the other stages only with RT_RENDER_TIME_STAGES.  The event pairs are cached in the context.
-    constexpr int N_STAGES = 6;  // generate, extend, shade, shadow, compact, tail
+    constexpr int N_STAGES = 6;  // generate, extend, shade, shadow, publish ("compact"), mixed + tail
     float stage_ms[N_STAGES] = {0, 0, 0, 0, 0, 0};
     struct Span {
         int stage;
@@ -1045,13 +1023,16 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     auto timed = [&](int k) { return timing || k == 1 || k == 5; };
     auto t_begin = [&](int k) -> int {
         if (!timed(k)) return RT_OK;
-        if (pairs_used == ctx->ev_pool.size() / 2) {
+        if (pairs_used == ctx->ev_pool.size() / 2) {  // the pool only ever holds complete pairs
             hipEvent_t e0 = nullptr, e1 = nullptr;
             RT_HIP(hipEventCreate(&e0));
+            const hipError_t e = hipEventCreate(&e1);
+            if (e != hipSuccess) {
+                (void)hipEventDestroy(e0);
+                RT_HIP(e);
+            }
             ctx->ev_pool.push_back(e0);
-            hipError_t e = hipEventCreate(&e1);
-            ctx->ev_pool.push_back(e1);  // a null second event is destroyed safely by rt_destroy
-            RT_HIP(e);
+            ctx->ev_pool.push_back(e1);
         }
         spans.push_back({k, pairs_used});
         RT_HIP(hipEventRecord(ctx->ev_pool[2 * pairs_used], stream));
@@ -1088,54 +1069,53 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     rp.k0 = (uint32_t)seed;
     rp.k1 = (uint32_t)(seed >> 32);
     const TuneBase tune = rt_tune_base();
-    uint32_t* const work_ext = pa.work;                   // closest-hit launches and the tail kernel
-    uint32_t* const work_sh = pa.work + rtd::WORK_U32;    // shadow and mixed launches
 
     // kernel selection by counting mode / scene features, one place each
-    auto launch_extend = [&](int grid, const PathArrays& pa, const uint32_t* queue, const uint32_t* cnt, uint32_t first) {
+    auto launch_extend = [&](int grid, const PathArrays& q, uint32_t first) {
         if (count == rtd::COUNT_REFERENCE)
-            hipLaunchKernelGGL(k_extend<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_extend<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, first, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
-            hipLaunchKernelGGL(k_extend<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_extend<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, first, tune, overflow, ostride);
         else if (lean)
-            hipLaunchKernelGGL(k_extend_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_extend_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, first, tune, overflow, ostride);
         else
-            hipLaunchKernelGGL(k_extend<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, queue, cnt, first, work_ext, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_extend<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, first, tune, overflow, ostride);
     };
-    auto launch_shadow = [&](int grid, const PathArrays& pa, const uint32_t* cnt) {
+    auto launch_shadow = [&](int grid, const PathArrays& q) {
         if (count == rtd::COUNT_REFERENCE)
-            hipLaunchKernelGGL(k_shadow<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_shadow<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
-            hipLaunchKernelGGL(k_shadow<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_shadow<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, overflow, ostride);
         else if (lean)
-            hipLaunchKernelGGL(k_shadow_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_shadow_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, overflow, ostride);
         else
-            hipLaunchKernelGGL(k_shadow<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, cnt, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_shadow<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, overflow, ostride);
     };
-    auto launch_mixed = [&](int grid, const PathArrays& ps, const PathArrays& pa, const uint32_t* queue_next, uint32_t identity, const uint32_t* cnt) {
+    auto launch_mixed = [&](int grid, const PathArrays& q) {
         if (count == rtd::COUNT_REFERENCE)
-            hipLaunchKernelGGL(k_mixed<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_mixed<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
-            hipLaunchKernelGGL(k_mixed<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_mixed<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, overflow, ostride);
         else if (lean)
-            hipLaunchKernelGGL(k_mixed_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_mixed_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, overflow, ostride);
         else
-            hipLaunchKernelGGL(k_mixed<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, ps, pa, queue_next, cnt, identity, work_sh, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_mixed<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, overflow, ostride);
     };
-    auto launch_tail = [&](int grid, const PathArrays& pa, const uint32_t* queue, const uint32_t* cnt) {
+    auto launch_tail = [&](int grid, const PathArrays& q) {
         if (count == rtd::COUNT_REFERENCE)
-            hipLaunchKernelGGL(k_tail<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp, queue, cnt, work_ext, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_tail<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
-            hipLaunchKernelGGL(k_tail<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp, queue, cnt, work_ext, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_tail<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, tune, overflow, ostride);
         else
-            hipLaunchKernelGGL(k_tail<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, pa, rp, queue, cnt, work_ext, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_tail<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, tune, overflow, ostride);
     };
 
-    // What the host remembers of a bounce: which launches it enqueued, and the counts k_compact_scan_top published
-    // for it (read from pinned memory once the event recorded behind that kernel has completed).
+    // What the host remembers of a bounce: which launches it enqueued, and the counts k_publish wrote for it
+    // (read from pinned memory once the event recorded behind that kernel has completed).
     struct Bounce {
         bool extend = false, mixed = false, shadow = false, got = false;
         uint32_t n_next = 0, n_shadow = 0, n_skipped = 0;  // paths alive after the bounce, its shadow rays traced / not needed
+        uint32_t seg_max = 0;                              // survivors in the fullest segment
     };
     std::vector<Bounce> hist;
     auto wait_counts = [&](size_t k) -> int {
@@ -1145,6 +1125,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         hist[k].n_next = h[0];
         hist[k].n_shadow = h[1];
         hist[k].n_skipped = h[2];
+        hist[k].seg_max = h[3];
         hist[k].got = true;
         return RT_OK;
     };
@@ -1160,27 +1141,25 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         // every path's state from memory)
         const bool implicit = !user_rays && depth > 0 && !(use_tail && n_paths <= tail_paths) && getenv("RT_NO_IMPLICIT") == nullptr;
         rp.implicit_first = implicit ? 1u : 0u;
-        rp.identity_queue = 1u;
         rp.bounce = 0u;
-        RT_HIP(hipMemsetAsync(pa.work, 0, 2 * rtd::WORK_U32 * 4, stream));
+        // ---- the wavefront loop.  n_ub is an UPPER BOUND of the paths alive at bounce k (seg_ub: in its fullest
+        // segment): exact while bounces are big (the host waits for the counts of bounce k before it enqueues bounce
+        // k + 1: a round trip of tens of microseconds against launches of milliseconds, and exact counts pick the launch
+        // shapes), one bounce old once they are small (n_ub <= async_below): then the host enqueues bounce k + 1 while
+        // the device still works on bounce k, with grids sized from the counts of bounce k -- paths only die, in every
+        // segment, so they are bounds -- and every kernel takes its true counts from device memory.  That removes the
+        // host round trip and the idle gap behind it from every late bounce (0.1 ms each, profiles/r02/tuning.md).
+        hist.clear();
+        uint32_t n_ub = depth > 0 ? n_paths : 0;
+        ns_of.assign(2, segments_for(n_paths));
+        uint32_t seg_ub = std::min<uint64_t>(n_ub, (uint64_t)seg_cap * (NSEG / ns_of[0]));
+        RT_HIP(hipMemsetAsync(base + o_acc, 0, zero_bytes, stream));  // accumulators, skipped total, work counters
         if ((rc = t_begin(0)) != RT_OK) return rc;
-        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, reg[0], rp, n_paths, gen_rays);
+        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, view(0), rp, n_paths, gen_rays, counts);
         if ((rc = t_end(0)) != RT_OK) return rc;
         st.paths += n_paths;
         st.batches += 1;
 
-        // ---- the wavefront loop.  n_ub is an UPPER BOUND of the paths alive at bounce k: exact while bounces are big
-        // (the host waits for the counts of bounce k before it enqueues bounce k + 1: a round trip of tens of
-        // microseconds against launches of milliseconds, and exact counts pick the launch shapes), one bounce old once
-        // they are small (n_ub <= async_below): then the host enqueues bounce k + 1 while the device still works on
-        // bounce k, with grids sized from the count of bounce k -- paths only die, so it is a bound -- and every
-        // kernel takes its true n from device memory.  That removes the host round trip and the idle gap behind it
-        // from every late bounce (0.1 ms each, profiles/r02/tuning.md).
-        hist.clear();
-        uint32_t n_ub = depth > 0 ? n_paths : 0;
-        int rcur = 0;               // region the live paths are in
-        int cur = 0;                // which of the region's two queues holds them ...
-        bool ident = true;          // ... unless queue position = slot (first bounce, after a moving compaction)
         size_t k = 0;
         uint32_t tail_iters_total = 0;
         bool extend_done = false;  // the rays of this bounce were traced by the previous bounce's mixed launch
@@ -1189,17 +1168,17 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
                 rth::set_error("rt_render: wavefront did not drain after 2^20 iterations");
                 return RT_ERR_LIMIT;
             }
-            const PathArrays& pr = reg[rcur];
-            const uint32_t* cnt_in = pa.counts + 4 * (k & 1);
-            uint32_t* cnt_out = pa.counts + 4 * ((k + 1) & 1);
+            // the survivors of this bounce are at most n_ub: that picks the next bounce's segments
+            if (ns_of.size() < k + 2) ns_of.resize(k + 2);
+            ns_of[k + 1] = std::min(ns_of[k], segments_for(n_ub));
+            const PathArrays pr = view(k);
             rp.bounce = (uint32_t)k + 1;  // iteration k of `while depth > 0` draws from RNG bounce k+1 (bounce 0: camera jitter)
             const uint32_t first_implicit = (implicit && k == 0) ? 1u : 0u;
             rp.implicit_first = first_implicit;
-            rp.identity_queue = ident ? 1u : 0u;
             if (use_tail && n_ub <= tail_paths) {  // few paths left: one launch takes them to their end
                 RT_HIP(hipMemsetAsync(pa.tail + 6, 0, 8, stream));
                 if ((rc = t_begin(5)) != RT_OK) return rc;
-                launch_tail(rt_trace_grid(n_ub), pr, pr.queue[cur], cnt_in);
+                launch_tail(rt_trace_grid(n_ub), pr);
                 if ((rc = t_end(5)) != RT_OK) return rc;
                 unsigned long long tail_iters = 0;
                 RT_HIP(hipMemcpyAsync(&tail_iters, pa.tail + 6, 8, hipMemcpyDeviceToHost, stream));
@@ -1216,72 +1195,59 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
             hist.emplace_back();
             if (!extend_done) {
                 if ((rc = t_begin(1)) != RT_OK) return rc;
-                launch_extend(rt_trace_grid(n_ub), pr, pr.queue[cur], cnt_in, first_implicit ? 1u : (ident ? 2u : 0u));
+                launch_extend(rt_trace_grid(n_ub), pr, first_implicit);
                 if ((rc = t_end(1)) != RT_OK) return rc;
                 hist[k].extend = true;
             }
             extend_done = false;
 
-            const uint32_t n_blocks = (n_ub + SHADE_BLOCK - 1) / SHADE_BLOCK;
+            // shade + compaction: NSEG interleaved segments, grid sized from the fullest one
+            const uint32_t seg_blocks = (seg_ub + SHADE_BLOCK - 1) / SHADE_BLOCK;
             if ((rc = t_begin(2)) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pr, rp, pr.queue[cur], cnt_in);
+            hipLaunchKernelGGL(k_shade, dim3(seg_blocks * pr.ns), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pr, rp);
             if ((rc = t_end(2)) != RT_OK) return rc;
-
+            if (ns_of.size() < k + 3) ns_of.resize(k + 3, ns_of[k + 1]);
+            ns_of[k + 2] = ns_of[k + 1];  // placeholder until bounce k + 1 decides it (view(k + 1) only uses it for its own shade)
+            const PathArrays pn = view(k + 1);  // the next bounce: the other region, the counts k_publish writes now
             if ((rc = t_begin(4)) != RT_OK) return rc;
-            const uint32_t n_groups = (n_blocks + SCAN_GROUP - 1) / SCAN_GROUP;
-            hipLaunchKernelGGL(k_compact_scan_groups, dim3(n_groups), dim3(1024), 0, stream, pr, cnt_in);
-            hipLaunchKernelGGL(k_compact_scan_top, dim3(1), dim3(1024), 0, stream, pr, cnt_in, cnt_out,
-                               ctx->rb_host + 4 * (k % RT_READBACK_RING));
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, stream, pr, (uint32_t*)pn.cnt, ctx->rb_host + 4 * (k % RT_READBACK_RING));
             if ((rc = t_end(4)) != RT_OK) return rc;
             RT_HIP(hipEventRecord(ctx->rb_ev[k % RT_READBACK_RING], stream));
 
             // bounds of the next bounce's rays and of this bounce's shadow rays
-            uint32_t nn_ub, ns_ub;
+            uint32_t nn_ub, ns_ub, ng_ub;
             if (n_ub > async_below) {  // big bounce: wait for its exact counts
                 if ((rc = wait_counts(k)) != RT_OK) return rc;
                 nn_ub = hist[k].n_next;
                 ns_ub = hist[k].n_shadow;
-                if (nn_ub > n_ub || ns_ub > n_ub) {
+                ng_ub = hist[k].seg_max;
+                if (nn_ub > n_ub || ns_ub > n_ub || ng_ub > nn_ub) {
                     rth::set_error("rt_render: compaction produced impossible counts");
                     return RT_ERR_HIP;
                 }
             } else {  // small bounce: the counts of the bounce BEFORE it have arrived meanwhile (or will, without idling the device)
                 if (k > 0 && (rc = wait_counts(k - 1)) != RT_OK) return rc;
                 nn_ub = ns_ub = k > 0 ? std::min(n_ub, hist[k - 1].n_next) : n_ub;
+                // (the fullest of the next bounce's segments holds at most the survivors of the ns / ns_out segments it merges)
+                ng_ub = (uint32_t)std::min<uint64_t>(nn_ub, (uint64_t)(k > 0 ? std::min(seg_ub, hist[k - 1].seg_max) : seg_ub) * (ns_of[k] / ns_of[k + 1]));
             }
-            // moving compaction: the survivors' state goes to a dense region as soon as one can hold them
-            const bool move = use_move && nn_ub > 0 && nn_ub <= Rcap;
-            const int rnext = move ? (rcur == 1 ? 2 : 1) : rcur;
-            const PathArrays& pn = reg[rnext];
-            if ((rc = t_begin(4)) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_compact_scatter, dim3(n_blocks), dim3(SHADE_BLOCK), 0, stream, pr, pr.queue[cur],
-                               pr.queue[cur ^ 1], cnt_in, ident ? 1u : 0u, pn, move ? 1u : 0u);
-            if ((rc = t_end(4)) != RT_OK) return rc;
-            const uint32_t* queue_next = move ? pn.queue[0] : pr.queue[cur ^ 1];
 
             const bool tail_next = use_tail && nn_ub <= tail_paths;  // the tail kernel traces its own first ray
             if (use_mix && ns_ub > 0 && nn_ub > 0 && !tail_next && (uint64_t)ns_ub + nn_ub <= mix_paths) {
                 // the shadow rays of this bounce and the rays of the next one in one launch
                 if ((rc = t_begin(5)) != RT_OK) return rc;
-                launch_mixed(rt_trace_grid((size_t)ns_ub + nn_ub), pr, pn, queue_next, move ? 1u : 0u, cnt_out);
+                launch_mixed(rt_trace_grid((size_t)ns_ub + nn_ub), pn);
                 if ((rc = t_end(5)) != RT_OK) return rc;
                 hist[k].mixed = true;
                 extend_done = true;
             } else if (ns_ub > 0) {
                 if ((rc = t_begin(3)) != RT_OK) return rc;
-                launch_shadow(rt_trace_grid(ns_ub), pr, cnt_out);
+                launch_shadow(rt_trace_grid(ns_ub), pn);
                 if ((rc = t_end(3)) != RT_OK) return rc;
                 hist[k].shadow = true;
             }
             n_ub = nn_ub;
-            rcur = rnext;
-            if (move) {
-                cur = 0;
-                ident = true;
-            } else {
-                cur ^= 1;
-                ident = false;
-            }
+            seg_ub = ng_ub;
             ++k;
         }
         // ---- what was traced, from the counts of every bounce (all arrived by now or after this wait)
