@@ -172,18 +172,22 @@ def main():
         if use_dist:
             reduce_kind = "torch.distributed"
             if not args.torch_reduce:
-                # rank 0 creates the unique id; byte 128 says whether it could (every rank takes part in the broadcast either way)
-                uid = torch.zeros(rt.api.COMM_ID_BYTES + 1, dtype=torch.uint8, device=dev)
-                if rank == 0:
+                # Every rank first checks that it can reach RCCL through the library at all (rt_comm_unique_id binds
+                # librccl and calls ncclGetUniqueId: cheap, not collective) and the ranks vote BEFORE anyone enters the
+                # collective ncclCommInitRank: a rank that fails there leaves the others blocked inside it.
+                my_id, can = None, 1
+                try:
+                    my_id = rt.comm_unique_id()
+                except rt.RtError as e:
+                    can = 0
+                    print(f"bench: rank {rank}: RCCL not reachable through the library ({e}); reducing with torch.distributed", file=sys.stderr)
+                ok = torch.tensor([can], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 1:
+                    uid = torch.tensor(list(my_id), dtype=torch.uint8, device=dev)  # rank 0's id is the communicator's
+                    dist.broadcast(uid, src=0)
                     try:
-                        uid = torch.tensor(list(rt.comm_unique_id()) + [1], dtype=torch.uint8, device=dev)
-                    except rt.RtError as e:
-                        print(f"bench: rt_comm_unique_id failed ({e}); reducing with torch.distributed", file=sys.stderr)
-                dist.broadcast(uid, src=0)
-                uid = uid.cpu().tolist()
-                if uid[-1] == 1:
-                    try:
-                        comm = rt.Comm(ctx, bytes(uid[:-1]), world, rank)
+                        comm = rt.Comm(ctx, bytes(uid.cpu().tolist()), world, rank)
                         reduce_kind = "rt_reduce_accum (RCCL, C ABI)"
                     except rt.RtError as e:  # plumbing fallback for the collective only; labelled in the output
                         print(f"bench: rt_comm_create failed on rank {rank} ({e}); reducing with torch.distributed", file=sys.stderr)
@@ -260,7 +264,7 @@ def main():
         ext = kernels["k_extend" + lean_sfx]
         result.update(kernel="k_extend" + lean_sfx, kernel_ms=ext["kernel_ms"], alg_bytes=ext["alg_bytes"],
                       launches=int(launches), ms_extend=ms_extend_timed, ms_shadow=st.ms_shadow, ms_shade=st.ms_shade,
-                      ms_generate=st.ms_generate, ms_compact=st.ms_compact, ms_tail=st.ms_tail,
+                      ms_generate=st.ms_generate, ms_publish=st.ms_compact, ms_mixed_tail=st.ms_tail,
                       paths_tail=int(st.paths_tail), ms_device_total=st.ms_total,
                       n_int_mean=st_count.nodes_visited / max(1, st_count.rays_closest),
                       n_tri_mean=st_count.tris_tested / max(1, st_count.rays_closest),

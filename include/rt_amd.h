@@ -269,10 +269,11 @@ int rt_trace_any(rt_ctx* ctx, const rt_rays* rays, size_t n, float t_min, float 
                  uint8_t* occluded, uint32_t* n_int, uint32_t* n_tri);
 
 /* Allocation-free form of rt_trace_closest.  NO counterpart in the reference: it exists for callers that cannot
-   call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+   call hipMalloc -- tight serving loops, harnesses that forbid allocation.  (Not capturable into a HIP graph as it
+   stands: it launches on the context's own stream and synchronises it before it returns.)  Same
    results as rt_trace_closest, bit for bit, but it calls no hipMalloc / hipFree / allocating routine: the
    launch's scratch (work counters + traversal-stack overflow strips) lives in a static device array of
-   24.008 MiB that every GPU the library runs on holds until the process ends.  Limits: every ray / hit array
+   24.016 MiB that every GPU the library runs on holds until the process ends.  Limits: every ray / hit array
    must be DEVICE memory (no staging), n <= RT_NOALLOC_MAX_RAYS, and the scene's deepest BVH must not exceed
    RT_NOALLOC_MAX_STACK_DEPTH levels (RT_ERR_LIMIT otherwise).  All calls on one GPU share the static array:
    calls that overlap on the same GPU (two contexts, two threads) race; serialise them. */

@@ -715,7 +715,10 @@ int rt_ray_colour(rt_ctx* ctx, const rt_rays* rays, size_t n, uint32_t spp_first
         rth::set_error("rt_ray_colour: null argument");
         return RT_ERR_INVALID;
     }
-    if (n == 0) return RT_OK;
+    if (n == 0) {  // nothing to write into rgb_sum; the statistics are those of an empty render
+        if (stats) memset(stats, 0, sizeof *stats);
+        return RT_OK;
+    }
     if (n > 0x7FFFFFFFull) {
         rth::set_error("rt_ray_colour: batch larger than 2^31 - 1 rays");
         return RT_ERR_LIMIT;

@@ -858,29 +858,30 @@ bool is_device_ptr(const void* p) {
 // rt_ray_colour (user_rays: device pointers to `width` caller rays, height 1; "pixel" k is ray k).
 int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* user_rays, uint32_t spp_first,
                    uint32_t spp_count, uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, rt_stats* stats) {
+    const char* const who = user_rays ? "rt_ray_colour" : "rt_render";  // the entry point the caller knows
     if (!ctx || !rgb_sum) {
-        rth::set_error("rt_render: null argument");
+        rth::set_error("%s: null argument", who);
         return RT_ERR_INVALID;
     }
     if (!ctx->has_scene) {
-        rth::set_error("rt_render: no scene uploaded (call rt_upload_scene first)");
+        rth::set_error("%s: no scene uploaded (call rt_upload_scene first)", who);
         return RT_ERR_STATE;
     }
     if (!user_rays && (width < 2 || height < 2)) {  // the reference divides by (w-1), (h-1) (:303-304)
-        rth::set_error("rt_render: width and height must be >= 2");
+        rth::set_error("%s: width and height must be >= 2", who);
         return RT_ERR_INVALID;
     }
     const rt_rays no_rays = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const rt_rays gen_rays = user_rays ? *user_rays : no_rays;
     const uint64_t npix64 = (uint64_t)width * height;
     if (npix64 > 0x7FFFFFFFull) {
-        rth::set_error("rt_render: image too large");
+        rth::set_error("%s: image too large", who);
         return RT_ERR_LIMIT;
     }
     const uint32_t npix = (uint32_t)npix64;
     if (ctx->scene.n_lights == 0 && ctx->scene.n_objects > 0) {
         // sample_lights_uniform would index an empty Vec (panic) on the first non-specular hit
-        rth::set_error("rt_render: scene has no lights (the reference panics in sample_lights_uniform)");
+        rth::set_error("%s: scene has no lights (the reference panics in sample_lights_uniform)", who);
         return RT_ERR_INVALID;
     }
     RT_HIP(hipSetDevice(ctx->device));
@@ -1165,7 +1166,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         bool extend_done = false;  // the rays of this bounce were traced by the previous bounce's mixed launch
         while (n_ub > 0) {
             if (k >= (size_t)1 << 20) {
-                rth::set_error("rt_render: wavefront did not drain after 2^20 iterations");
+                rth::set_error("%s: wavefront did not drain after 2^20 iterations", who);
                 return RT_ERR_LIMIT;
             }
             // the survivors of this bounce are at most n_ub: that picks the next bounce's segments
@@ -1222,7 +1223,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
                 ns_ub = hist[k].n_shadow;
                 ng_ub = hist[k].seg_max;
                 if (nn_ub > n_ub || ns_ub > n_ub || ng_ub > nn_ub) {
-                    rth::set_error("rt_render: compaction produced impossible counts");
+                    rth::set_error("%s: compaction produced impossible counts", who);
                     return RT_ERR_HIP;
                 }
             } else {  // small bounce: the counts of the bounce BEFORE it have arrived meanwhile (or will, without idling the device)
@@ -1256,7 +1257,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
             if ((rc = wait_counts(b)) != RT_OK) return rc;
             const uint32_t n_b = b > 0 ? hist[b - 1].n_next : n_paths;  // paths alive at bounce b
             if (hist[b].n_next > n_b || hist[b].n_shadow > n_b) {
-                rth::set_error("rt_render: compaction produced impossible counts");
+                rth::set_error("%s: compaction produced impossible counts", who);
                 return RT_ERR_HIP;
             }
             if (n_b == 0) continue;  // a bounce enqueued on a stale bound after the last path had died

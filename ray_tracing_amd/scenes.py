@@ -186,6 +186,24 @@ def baby_yoda_scene(stl_path, sigma_s=0.0, extra_mesh_levels=None):
     return s
 
 
+def teapot_scene(stl_path, divisions=1):
+    """scene_teapot, src/main.rs:165-211: utah_teapot.stl through read_stl (stl.rs:8-143; 9 438 triangles, an OPEN mesh:
+    the Loop rules for boundary vertices and edges apply, subdivision_surface.rs:169-173, :218-232), loop_subdivide(.., 1)
+    (37 752 triangles), Diffuse (0.9, 0.3, 0.3); ground plane at the subdivided mesh's lowest vertex; PointLight at
+    100 * (1, 0, 1); camera at centroid + new_polar(18, 0.3 pi, 0.5 pi) looking at the volume centroid."""
+    s = SceneDescription()
+    mesh = Mesh.read_stl(stl_path).loop_subdivide(divisions)
+    verts = mesh.arrays()[0]
+    ground = F(np.min(verts[:, 2]))
+    s.add_mesh(mesh, s.diffuse((0.9, 0.3, 0.3)))
+    s.add_plane((0.0, 0.0, float(ground)), (0.0, 0.0, 1.0), s.diffuse((0.8, 0.8, 0.8)))
+    centre = mesh.volume_centroid()
+    d = new_polar(18.0, F(0.3) * PI, F(0.5) * PI)
+    s.look_at((centre + d).astype(np.float32), centre, ASPECT_RATIO)
+    s.point_light(F(100.0) * np.array([1.0, 0.0, 1.0], np.float32), (60000.0, 60000.0, 60000.0))
+    return s
+
+
 def spotlight_scene(levels=3):
     """Spotlight (lights.rs:49-75) next to a PointLight: a subdivided tetrahedron and a glass ball over a ground
     plane.  The cone (cos_angle 0.9) covers the mesh and part of the plane, so shading points fall on both sides

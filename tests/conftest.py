@@ -19,3 +19,13 @@ def ctx():
     c = rt.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _reset_shared_context(request):
+    """Tests that switch the shared context's visit-count mode reset it themselves on the success path only; a failed
+    assertion in one of them must not change what the tests after it measure."""
+    yield
+    if "ctx" in request.fixturenames:
+        import ray_tracing_amd as rt
+        request.getfixturevalue("ctx").set_visit_count_mode(rt.api.COUNT_REFERENCE)

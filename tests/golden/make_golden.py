@@ -23,6 +23,7 @@ CASES = {  # name -> (scene description factory, width, spp, depth, seed)
     "config4_homogeneous_medium": (lambda: scenes.path_scene(levels=3, glass_levels=2, medium=True, sigma_s=2.0), 48, 4, 16, 14),
     "primitives_conductor": (lambda: scenes.primitives_scene(), 64, 4, 16, 15),
     "stl_baby_yoda_medium": (lambda: scenes.baby_yoda_scene(os.path.join(HERE, "baby_yoda.stl"), sigma_s=0.05, extra_mesh_levels=3), 64, 4, 16, 17),
+    "stl_utah_teapot_subdivided": (lambda: scenes.teapot_scene(os.path.join(HERE, "utah_teapot.stl")), 64, 4, 16, 18),
     "spotlight_and_point_light": (lambda: scenes.spotlight_scene(levels=3), 64, 4, 16, 16),
 }
 

@@ -48,7 +48,10 @@ from ray_tracing_amd import scenes
 from ray_tracing_amd.distributed import sample_shard
 if rank == 0:
     open(idfile + ".tmp", "wb").write(rt.comm_unique_id()); os.rename(idfile + ".tmp", idfile)
-while not os.path.exists(idfile):
+deadline = time.time() + 120.0
+while not os.path.exists(idfile):  # rank 0 may have died before it wrote the id: give up instead of spinning for ever
+    if time.time() > deadline:
+        sys.exit(1)
     time.sleep(0.05)
 uid = open(idfile, "rb").read()
 ctx = rt.Context(rank)
@@ -74,8 +77,14 @@ def test_reduce_world_size_2_sums_the_sample_shards(tmp_path):
     script.write_text(_RANK)
     idfile, out = str(tmp_path / "id.bin"), str(tmp_path / "sum.npy")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", idfile, out]) for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=300) == 0
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:  # a rank that is still alive (its peer died inside the collective init) must not keep holding a GPU
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     got = np.load(out)
     desc = scenes.path_scene(levels=3, glass_levels=2)
     orc = ob.OracleScene(desc)

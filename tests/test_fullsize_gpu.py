@@ -141,6 +141,29 @@ def test_stl_scene_full_resolution_subset(ctx):
     assert np.array_equal(img.reshape(-1, 3)[px].view(np.uint32), ref.view(np.uint32))
 
 
+def test_teapot_scene_full_resolution_subset(ctx):
+    """scene_teapot (src/main.rs:165-211; utah_teapot.stl Loop-subdivided twice: 151 008 triangles) at 1080p: pixels over
+    the teapot, over its shadow side of the ground and random ones against the oracle, bit for bit."""
+    import os
+    stl = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "utah_teapot.stl")
+    desc = scenes.teapot_scene(stl, divisions=2)
+    scene = rt.Scene(desc)
+    assert scene.flat.n_tris == 16 * 9438
+    ctx.upload(scene)
+    orc = ob.OracleScene(desc)
+    img, st = ctx.render(W, H, 4, 16, 23)
+    assert np.isfinite(img).all() and img.mean() > 0
+    org, dr = scenes.pixel_center_rays(scene.flat.camera, W, H)
+    objs = ctx.trace_closest(org, dr)["obj"]
+    pot, ground = np.flatnonzero(objs == 0), np.flatnonzero(objs == 1)
+    assert len(pot) > 100000 and len(ground) > 100000
+    px = np.concatenate([np.random.default_rng(7).choice(pot, 700, replace=False),
+                         np.random.default_rng(8).choice(ground, 300, replace=False),
+                         np.random.default_rng(9).choice(W * H, 200, replace=False)]).astype(np.uint32)
+    ref, _ = orc.render_pixels(W, H, px, 4, 16, 23, threads=8)
+    assert np.array_equal(img.reshape(-1, 3)[px].view(np.uint32), ref.view(np.uint32))
+
+
 def test_config5_full_size_distinct_meshes_4k(ctx):
     """configs[4] at its stated size: 3840x2160, 64 spp, ten 1 048 576-triangle meshes each with its OWN BVH
     (10.5 M triangles, 1.1 GB of child pairs and triangles -- beyond the Infinity Cache), rendered by one GPU (the

@@ -123,6 +123,18 @@ def test_stl_fed_scene_baby_yoda(ctx):
     _check(ctx, scenes.baby_yoda_scene(STL, sigma_s=0.05, extra_mesh_levels=4), 96, 54, 4, 16, seed=8)
 
 
+def test_stl_fed_scene_teapot_loop_subdivided(ctx):
+    """scene_teapot (src/main.rs:165-211): the reference's other asset, an OPEN mesh, read_stl -> loop_subdivide(.., 1)
+    (boundary rules of the Loop scheme) -> BVH -> HIP path against the oracle; also two subdivisions (151 008 triangles,
+    SURVEY.md's config-3 alternative)."""
+    teapot = os.path.join(os.path.dirname(STL), "utah_teapot.stl")
+    desc = scenes.teapot_scene(teapot)
+    assert rt.Scene(desc).flat.n_tris == 4 * 9438
+    img, st, _ = _check(ctx, desc, 96, 54, 4, 16, seed=18)
+    assert img.mean() > 0 and st.rays_shadow > 0
+    _check(ctx, scenes.teapot_scene(teapot, divisions=2), 96, 54, 2, 16, seed=19)
+
+
 def test_batching_and_sample_offsets_do_not_change_the_image(ctx):
     desc = scenes.path_scene(levels=3, glass_levels=2)
     w, h = 64, 36

@@ -5,6 +5,7 @@ keeps the first call's contents)."""
 import numpy as np
 import pytest
 
+import oracle_binding as ob
 import ray_tracing_amd as rt
 from ray_tracing_amd import scenes
 
@@ -54,6 +55,26 @@ def test_noalloc_matches_rt_trace_closest_twice_second_smaller(ctx):
             assert (want["obj"] != -1).sum() > 100
             for k in want:
                 assert np.array_equal(got[k], want[k]), (counters, len(o), k)
+    # the property the entry point exists for: free device memory is the same before and after it (every kernel and
+    # buffer it can need exists by now; torch's caching allocator hands the arrays below out of memory it already holds)
+    cols, out = _device_batch(torch, org, dr)
+    ptrs = {k: v.data_ptr() for k, v in out.items()}
+    rays6 = [c.data_ptr() for c in cols]
+    ctx.trace_closest_noalloc(rays6, len(org), ptrs)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for n in (len(org), 9001, len(org)):
+        ctx.trace_closest_noalloc(rays6, n, ptrs)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0, "rt_trace_closest_noalloc changed the free device memory"
+    # ... and directly against the oracle, visit counters included (the child-pair walk counts the reference's visits)
+    orc = ob.OracleScene(desc)
+    sub = small[:4000]
+    got = _run(ctx, torch, org[sub], dr[sub], True, True)
+    want = orc.trace_closest(org[sub], dr[sub])
+    assert np.array_equal(got["prim"].view(np.uint32), want["prim"]) and np.array_equal(got["obj"].view(np.uint32), want["obj"])
+    assert np.array_equal(got["t"].view(np.uint32), want["t"].view(np.uint32))
+    assert np.array_equal(got["n_int"].view(np.uint32), want["n_int"]) and np.array_equal(got["n_tri"].view(np.uint32), want["n_tri"])
     # two allocation-free calls back to back, the second smaller, each against the existing entry point
     a1 = _run(ctx, torch, org, dr, True, True)
     a2 = _run(ctx, torch, org[small], dr[small], True, True)
