@@ -545,6 +545,7 @@ template <bool LATE_IN, bool LATE_OUT>
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa, RenderParams rp) {
     static_assert(LATE_OUT || !LATE_IN, "records stay records");
     __shared__ uint32_t wave_cnt[3][SHADE_BLOCK / 64];
+    __shared__ uint32_t wave_max[SHADE_BLOCK / 64];
     __shared__ uint32_t base[2];
     const uint32_t seg = blockIdx.x % pa.ns, first = (blockIdx.x / pa.ns) * SHADE_BLOCK;
     const uint32_t n = pa.cnt[CNT_ALIVE + seg];
@@ -554,6 +555,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     uint32_t flags = 0, bounce = rp.bounce;
     bool shaded = false;
     ShadeOut out;
+    if constexpr (LATE_OUT) {  // every field of a record is written, whatever shade_path filled in
+        out.d4 = out.b4 = out.sh_d = out.sh_c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     if (local < n) {
         const uint32_t slot = seg0 + local;
         if constexpr (LATE_IN) {
@@ -561,13 +565,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
             const uint32_t mode = __float_as_uint(s4.w);
             bounce = pa.pbounce[slot];
             if (mode & M_SUSP) {
-                out.o4 = pa.ray_o[slot];
-                out.d4 = pa.ray_d[slot];
-                out.b4 = pa.beta[slot];
-                out.id = pa.oid[slot];
-                out.sh_d = s4;
-                out.sh_c = pa.sh_c[slot];
-                flags = QF_CARRY;
+                flags = QF_CARRY;  // copied from position to position below
             } else if (mode & M_ALIVE) {
                 flags = shade_path(sc, pa, rp, slot, bounce, out);
                 shaded = true;
@@ -590,13 +588,18 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     if constexpr (LATE_IN) {  // rt_stats::iterations: the highest bounce index any path was shaded at
         uint32_t mb = shaded ? bounce : 0u;
         for (int off = 32; off > 0; off >>= 1) mb = max(mb, (uint32_t)__shfl_down((int)mb, off));
-        if (lane == 0 && mb) atomicMax(&pa.tail[8], (unsigned long long)mb);
+        if (lane == 0) wave_max[wave] = mb;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t[3] = {0, 0, 0};
         for (int w = 0; w < SHADE_BLOCK / 64; ++w)
             for (int q = 0; q < 3; ++q) t[q] += wave_cnt[q][w];
+        if constexpr (LATE_IN) {  // one look at the maximum so far (any stale value only costs an atomic), one atomic if this block raises it
+            uint32_t mb = 0;
+            for (int w = 0; w < SHADE_BLOCK / 64; ++w) mb = max(mb, wave_max[w]);
+            if (mb > (uint32_t)__hip_atomic_load(&pa.tail[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&pa.tail[8], (unsigned long long)mb);
+        }
         unsigned long long r = 0ull;
         if (t[0] | t[1]) r = atomicAdd(&pa.acc[oseg * ACC_STRIDE], (unsigned long long)t[0] | ((unsigned long long)t[1] << 32));
         base[0] = (uint32_t)r;
@@ -608,18 +611,28 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     if (goes_on) {
         uint32_t pos = oseg0 + base[0] + (uint32_t)__popcll(alive & below);
         for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[0][w];
-        pa.nray_o[pos] = out.o4;
-        pa.noid[pos] = out.id;
-        if constexpr (LATE_OUT) {
-            const bool carry = (flags & QF_CARRY) != 0, live = (flags & (QF_ALIVE | QF_CARRY)) != 0, sh = (flags & (QF_SHADOW | QF_CARRY)) != 0;
-            const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            pa.nray_d[pos] = live ? out.d4 : zero;
-            pa.nbeta[pos] = live ? out.b4 : zero;
-            pa.npbounce[pos] = carry ? bounce : bounce + 1u;
-            const uint32_t mode = ((flags & QF_SHADOW) ? M_SHADOW : 0u) | ((flags & QF_ALIVE) ? M_ALIVE : 0u);
-            pa.nsh_d[pos] = carry ? out.sh_d : make_float4(sh ? out.sh_d.x : 0.0f, sh ? out.sh_d.y : 0.0f, sh ? out.sh_d.z : 0.0f, __uint_as_float(mode));
-            pa.nsh_c[pos] = sh ? out.sh_c : zero;
+        if (LATE_IN && (flags & QF_CARRY)) {  // a walk set aside: the record as it is (its mode names the state slot)
+            const uint32_t slot = seg0 + local;
+            pa.nray_o[pos] = pa.ray_o[slot];
+            pa.nray_d[pos] = pa.ray_d[slot];
+            pa.nbeta[pos] = pa.beta[slot];
+            pa.noid[pos] = pa.oid[slot];
+            pa.npbounce[pos] = bounce;
+            pa.nsh_d[pos] = pa.sh_d[slot];
+            pa.nsh_c[pos] = pa.sh_c[slot];
+        } else if constexpr (LATE_OUT) {
+            const bool live = (flags & QF_ALIVE) != 0, sh = (flags & QF_SHADOW) != 0;
+            pa.nray_o[pos] = out.o4;
+            pa.noid[pos] = out.id;
+            pa.nray_d[pos] = out.d4;
+            pa.nbeta[pos] = out.b4;
+            pa.npbounce[pos] = bounce + 1u;
+            const uint32_t mode = (sh ? M_SHADOW : 0u) | (live ? M_ALIVE : 0u);
+            pa.nsh_d[pos] = make_float4(out.sh_d.x, out.sh_d.y, out.sh_d.z, __uint_as_float(mode));
+            pa.nsh_c[pos] = out.sh_c;
         } else {
+            pa.nray_o[pos] = out.o4;
+            pa.noid[pos] = out.id;
             pa.nray_d[pos] = out.d4;
             pa.nbeta[pos] = out.b4;
         }
@@ -812,7 +825,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, Ren
 
 // The same for the RECORDS of a late region: a record's pending shadow ray comes first, a walk k_late set aside goes on
 // where it stopped, every path is shaded with its own bounce index (pa.tail[8]: the highest one).
-__global__ __launch_bounds__(RT_BLOCK) void k_tail_rec(DScene sc, PathArrays pa, RenderParams rp, TuneBase base, uint32_t* overflow,
+#ifndef RT_WAVES_EU_TAIL_REC
+#define RT_WAVES_EU_TAIL_REC 2
+#endif
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_TAIL_REC))) void k_tail_rec(DScene sc, PathArrays pa, RenderParams rp, TuneBase base, uint32_t* overflow,
                                                        uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1324,6 +1340,10 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         const char* e = getenv("RT_TAIL_PATHS_LATE");
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 4096u;
     }();
+    static const bool late_tail_at_end = [] {
+        const char* e = getenv("RT_LATE_TAIL_AT_END");
+        return e ? atoi(e) != 0 : true;
+    }();
     // RT_RENDER_LATE_STRESS / _STRESS2 (tests): records from the first bounce on, a budget of three iterations -- nearly
     // every walk is set aside, most of them several times -- and the tail kernel only for the last 64 records / for
     // whatever is left after two late rounds (records with pending shadow rays and walks set aside).
@@ -1335,7 +1355,10 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     auto tail_threshold = [&](size_t k) -> uint32_t {  // ... and for bounce k, whose paths are late[k] ? records : not
         if (!late[k]) return tail_paths_big;
         if (stress2) return k >= 3 ? 0xFFFFFFFFu : 0u;
-        return stress ? 64u : tail_paths_late_env;
+        if (stress) return 64u;
+        // past the round in which the paths that were never set aside have ended, what is left are the paths that fell
+        // behind: one launch to their end instead of a round of three launches per bounce
+        return (k >= depth && late_tail_at_end) ? 0xFFFFFFFFu : tail_paths_late_env;
     };
     const bool timing = (flags & RT_RENDER_TIME_STAGES) != 0;
     // HIP events on the library's stream around every launch of a stage, summed per stage after the frame's last
