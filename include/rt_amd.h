@@ -320,10 +320,6 @@ typedef struct rt_stats {
                                       top-level cull active): the fetches the roofline figure prices */
 #define RT_RENDER_NO_TAIL 4u      /* keep one launch per stage and bounce to the end (no tail kernel) */
 #define RT_RENDER_TIME_STAGES 2u  /* fill every per-stage ms_* field (adds event records); ms_extend is always filled */
-#define RT_RENDER_LATE_STRESS 16u  /* tests only: the late-round machinery (records, budgeted launches that set walks aside and
-                                      resume them) from the first bounce on with a budget of three iterations; same image */
-#define RT_RENDER_LATE_STRESS2 32u /* tests only: the same, and the tail kernel takes over after two late rounds (records with
-                                      pending shadow rays and walks set aside) */
 
 /* Engine::render (path_integrator.rs:278-318) minus the PPM text: for every pixel (i, j) adds
    ray_colour (:138-276) of samples [spp_first, spp_first+spp_count) IN SAMPLE ORDER and stores the

@@ -20,7 +20,6 @@ LIGHT_POINT, LIGHT_SPOT, LIGHT_AREA = range(3)
 MEDIUM_HOMOGENEOUS, MEDIUM_CHECKERED = range(2)
 MEDIUM_NONE, MEDIUM_AUTO = -1, -2
 RENDER_COUNT_VISITS, RENDER_TIME_STAGES, RENDER_NO_TAIL, RENDER_COUNT_FETCHES = 1, 2, 4, 8
-RENDER_LATE_STRESS, RENDER_LATE_STRESS2 = 16, 32  # tests only (include/rt_amd.h)
 COUNT_REFERENCE, COUNT_FETCHES = 0, 1
 
 f32p = C.POINTER(C.c_float)

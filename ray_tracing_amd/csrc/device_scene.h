@@ -93,10 +93,6 @@ struct Stack {
         else overflow[(size_t)(sp - STACK_LDS) * overflow_stride] = v;
         ++sp;
     }
-    RT_DEV uint32_t at(int l) const {  // entry l (0 = bottom), for saving a suspended lane's stack
-        if (!OVERFLOW || l < STACK_LDS) return lds[l * BLOCK];
-        return overflow[(size_t)(l - STACK_LDS) * overflow_stride];
-    }
     RT_DEV uint32_t pop() {
         --sp;
         uint32_t v;

@@ -42,8 +42,6 @@ struct TraceTune {
     uint32_t refill_min;  // idle lanes that trigger a refill
     uint32_t w_adv, w_node, w_leaf;  // phase weights: each loop iteration runs the ONE phase with the largest
                                      // (lanes waiting for it) x weight
-    uint32_t budget;      // IO policies that can suspend a ray (IO::SUSPENDS): wave iterations a lane may spend on one
-                          // item before its state is set aside for the next launch; 0xFFFFFFFF = never
 };
 
 // The launch-independent part of TraceTune (host: rt_tune_base(); RT_TUNE overrides it) and the rule that sizes the
@@ -53,7 +51,6 @@ struct TraceTune {
 struct TuneBase {
     uint32_t chunk;  // 0 = by size: 128 rays per atomic on frame-sized launches, 64 on small ones (finer tail balance)
     uint32_t refill_min, w_adv, w_node, w_leaf, max_seg;
-    uint32_t budget;  // TraceTune::budget of the launches that can suspend rays (rt_render's late rounds)
 };
 __host__ __device__ inline TraceTune make_tune(const TuneBase& b, uint32_t n, uint32_t grid) {
     TraceTune t;
@@ -62,7 +59,6 @@ __host__ __device__ inline TraceTune make_tune(const TuneBase& b, uint32_t n, ui
     t.w_adv = b.w_adv;
     t.w_node = b.w_node;
     t.w_leaf = b.w_leaf;
-    t.budget = 0xFFFFFFFFu;
     // segments: at most max_seg, each at least 2048 chunks long (a drained segment costs every wave one probe),
     // never more than the launch has blocks
     uint32_t seg = n / (t.chunk * 2048u);
@@ -102,16 +98,6 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
 //   first_is_any(i)                        kind of the ray load() returned
 //   next(i, was_any, got, occluded, vis, &o, &d, &any) -> bool
 //                                          ray of item i finished; true = the lane continues with (o, d, any)
-//   CHAINS (TRACE_PATH, CONTINUES = false): next() may still return true -- the item has a second ray (rt_render's
-//   late rounds: a path's shadow ray, then its next ray) -- and the lane goes on with it at once, nothing is parked.
-//   SUSPENDS: the policy can set a ray aside (rt_render's late rounds; RenderLateIO in rt_render.hip).  A launch lasts as
-//   long as its longest ray -- hundreds of dependent fetches for one ray in ten thousand -- while every other lane of
-//   the chip idles.  A lane that has spent more than TraceTune::budget wave iterations on its item hands the loop's
-//   whole per-lane state (SavedLane: current object, node, t limits, flags, stack) to the policy and takes another
-//   item; a later launch hands it back and the walk goes on where it stopped -- the same node visits, triangle tests
-//   and t_max sequence as an uninterrupted walk, hence the same hit.
-//   suspend(i, lane_any, got, saved, stack words...) -> bool     false = no room: the lane keeps the ray
-//   resumes(i) -> const uint32_t*                                state of item i when it was suspended, else nullptr
 // FEAT: what the scene's objects can be (SceneFeatures).  The advance phase -- transforms, analytic
 // sphere and triangle objects -- is what sets the register count of the whole loop: 94 VGPRs with
 // everything, 72 with meshes and planes only, i.e. 5 against 7 waves per SIMD.  rt_upload_scene
@@ -120,14 +106,6 @@ enum SceneFeatures : uint32_t { FEAT_TRANSFORM = 1u, FEAT_SPHERE_TRIANGLE = 2u, 
 
 template <class IO, bool PATH> struct ParksLanes { static constexpr bool value = false; };
 template <class IO> struct ParksLanes<IO, true> { static constexpr bool value = IO::CONTINUES; };
-template <class IO, bool PATH> struct ChainsRays { static constexpr bool value = false; };
-template <class IO> struct ChainsRays<IO, true> { static constexpr bool value = IO::CHAINS; };
-template <class IO, bool PATH> struct SuspendsRays { static constexpr bool value = false; };
-template <class IO> struct SuspendsRays<IO, true> { static constexpr bool value = IO::SUSPENDS; };
-
-// A suspended lane: SAVED_WORDS u32 of state, then the traversal stack (sp entries, bottom first).
-constexpr uint32_t SAVED_CUR = 0, SAVED_OBJ = 1, SAVED_TMAX = 2, SAVED_BEST_T = 3, SAVED_HIT_TRI = 4, SAVED_FLAGS = 5, SAVED_SP = 6,
-                   SAVED_WORDS = 8;
 
 // COUNT: 0 = no visit counters; COUNT_REFERENCE = the reference's visits (no root-box skip, no top-level cull:
 // equal to the oracle's counters ray for ray); COUNT_FETCHES = the visits this loop performs when it is timed
@@ -149,11 +127,7 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     // A policy whose rays have no continuation (k_mixed: two kinds of ray, each finished for good) is served at
     // once like the single-kind kernels; only a policy that may hand the lane its NEXT ray parks it for phase D.
     constexpr bool PARK = ParksLanes<IO, PATH>::value;
-    constexpr bool CHAIN = ChainsRays<IO, PATH>::value;      // a finished ray may be followed at once by the item's next one
-    constexpr bool SUSPEND = SuspendsRays<IO, PATH>::value;  // rays over the launch's budget are set aside (see above)
-    static_assert(!SUSPEND || COUNT == COUNT_NONE, "a suspended lane's state has no room for visit counters");
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64u - lane));
     Stack<STACK_LDS, BLOCK, OVERFLOW> st;
     st.set_lds(lds);
     st.overflow = overflow;
@@ -200,7 +174,22 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
 #define RT_CYC(i)
 #endif
 
-    uint32_t it_now = 0, it_born = 0;  // SUSPEND: wave iterations so far (uniform), and at the lane's last refill
+    // a ray is finished: hand it to the IO policy now, or (TRACE_PATH) park the lane for phase D
+    auto finish = [&](bool occluded) {
+        if constexpr (PARK) {
+            cur = REF_DONE;
+            done_occluded = occluded;
+        } else if constexpr (PATH) {
+            V3 no, nd;
+            bool nany;
+            (void)io.next(ray, lane_any, got, occluded, vis, &no, &nd, &nany);
+            ray = RAY_NONE;
+        } else {
+            if constexpr (MODE == TRACE_ANY) io.emit_any(ray, occluded, vis);
+            else io.emit_closest(ray, got, vis);
+            ray = RAY_NONE;
+        }
+    };
     auto begin_ray = [&]() {
         best_t = t_max_in;
         got = false;
@@ -229,29 +218,6 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
             }
         }
     };
-    // a ray is finished: hand it to the IO policy now, or (TRACE_PATH) park the lane for phase D
-    auto finish = [&](bool occluded) {
-        if constexpr (PARK) {
-            cur = REF_DONE;
-            done_occluded = occluded;
-        } else if constexpr (PATH) {
-            V3 no = wo, nd = wd;
-            bool nany = false;
-            const bool chained = io.next(ray, lane_any, got, occluded, vis, &no, &nd, &nany);
-            if (CHAIN && chained) {  // the item's next ray, on this lane, from its first object (begin_ray's state)
-                wo = no;
-                wd = nd;
-                lane_any = nany;
-                begin_ray();
-            } else {
-                ray = RAY_NONE;
-            }
-        } else {
-            if constexpr (MODE == TRACE_ANY) io.emit_any(ray, occluded, vis);
-            else io.emit_closest(ray, got, vis);
-            ray = RAY_NONE;
-        }
-    };
     // the first object >= from that the ray can hit: `from` itself when its group is a candidate, else the first
     // object of the next candidate group (n_objects when there is none)
     auto next_cand = [&](uint32_t from) -> uint32_t {
@@ -264,28 +230,6 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
     };
 
     for (;;) {
-        // ---------------------------------------------------------------- set aside rays over the budget
-        if constexpr (SUSPEND) {
-            ++it_now;
-            if (ray != RAY_NONE && (!PARK || cur != REF_DONE) && it_now - it_born > tune.budget) {
-                uint32_t saved[SAVED_WORDS];
-                saved[SAVED_CUR] = cur;
-                saved[SAVED_OBJ] = obj;
-                saved[SAVED_TMAX] = __float_as_uint(tmax);
-                saved[SAVED_BEST_T] = __float_as_uint(best_t);
-                saved[SAVED_HIT_TRI] = hit_tri;
-                saved[SAVED_FLAGS] = (got ? 1u : 0u) | (hit_ff ? 2u : 0u) | (obj_hit ? 4u : 0u) | (fresh ? 8u : 0u);
-                saved[SAVED_SP] = (uint32_t)st.sp;
-                saved[7] = 0u;
-                uint32_t* rec = io.suspend(ray, lane_any, got, saved);  // null: no room, the lane keeps its ray
-                if (rec) {
-                    for (int l = 0; l < st.sp; ++l) rec[SAVED_WORDS + l] = st.at(l);
-                    ray = RAY_NONE;
-                } else {
-                    it_born = it_now;  // ask again a budget later
-                }
-            }
-        }
         // ---------------------------------------------------------------- refill idle lanes
         // The wave owns a pool [pool_next, pool_end) of consecutive ray indices; idle lanes draw
         // from it, and it is restocked `chunk` rays at a time from the launch's work counters.
@@ -341,46 +285,12 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
                 }
                 if (more) {
                     const uint32_t take = min(n_idle, pool_end - pool_next);  // pool_end > pool_next here
-                    const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));  // idle lanes below this one
                     if (idle && rank < take) {
                         const uint32_t idx = pool_next + rank;
                         ray = io.load(idx, &wo, &wd);
                         if constexpr (PATH) lane_any = io.first_is_any(idx);
                         begin_ray();
-                        if constexpr (SUSPEND) {
-                            it_born = it_now;
-                            if (const uint32_t* rec = io.resumes(ray)) {
-                                // the walk goes on where an earlier launch stopped it: begin_ray() has redone what depends
-                                // on the world ray alone (the candidate mask), the object-space ray is redone below with the
-                                // arithmetic of the advance phase, the rest was saved
-                                cur = rec[SAVED_CUR];
-                                obj = rec[SAVED_OBJ];
-                                tmax = __uint_as_float(rec[SAVED_TMAX]);
-                                best_t = __uint_as_float(rec[SAVED_BEST_T]);
-                                hit_tri = rec[SAVED_HIT_TRI];
-                                const uint32_t fl = rec[SAVED_FLAGS];
-                                got = (fl & 1u) != 0u;
-                                hit_ff = (fl & 2u) != 0u;
-                                obj_hit = (fl & 4u) != 0u;
-                                fresh = (fl & 8u) != 0u;
-                                const int sp = (int)min(rec[SAVED_SP], 64u);  // (never deeper than the deepest tree; a bound for the loop)
-                                st.sp = 0;
-                                for (int l = 0; l < sp; ++l) st.push(rec[SAVED_WORDS + l]);
-                                if (!fresh) {  // object.rs:39-45 for the object the walk is in (per-lane record: a vector load)
-                                    const DObject& ob = sc.objects[obj];
-                                    o = wo;
-                                    d = wd;
-                                    nr = 1.0f;
-                                    if ((FEAT & FEAT_TRANSFORM) && ob.has_transform) {
-                                        o = mat_mul(ob.inv_m, wo) + v3(ob.inv_t[0], ob.inv_t[1], ob.inv_t[2]);
-                                        d = mat_mul(ob.inv_m, wd);
-                                        nr = norm_recip(d);
-                                        d = d * nr;
-                                    }
-                                    inv = v3(recip(d.x), recip(d.y), recip(d.z));
-                                }
-                            }
-                        }
                     }
                     pool_next += take;
                     refilled = take > 0u;

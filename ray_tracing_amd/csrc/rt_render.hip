@@ -55,21 +55,6 @@ constexpr uint32_t ACC_STRIDE = 16;  // u64 between accumulators: one 128-byte l
 constexpr uint32_t CNT_SHADOW = 0, CNT_ALIVE = NSEG, CNT_TOT_ALIVE = 2 * NSEG, CNT_TOT_SHADOW = 2 * NSEG + 1, CNT_MIXED = 2 * NSEG + 4,
                    CNT_U32 = 4 * NSEG + 4;
 
-// Late rounds.  Once few paths are left a trace launch lasts as long as its longest ray (hundreds of dependent fetches
-// for one ray in ten thousand, ~0.4 ms) and a frame has a dozen such launches.  From the round whose paths number at
-// most RT_LATE_PATHS on, the pipeline therefore works on RECORDS: one per path that is alive or still has a shadow
-// ray to trace -- the vertex, the next ray, the throughput, the original slot, the RNG bounce index of the path's next
-// shade, the shadow direction with the record's MODE bits and the pending light term -- in two small ping-pong
-// regions.  k_late traces a record's shadow ray, adds the term, then traces its next ray (one lane, in the
-// reference's order for the path's radiance), under a BUDGET of wave iterations: a lane over it sets the walk aside
-// in a state slot (device_trace.h, SUSPENDS) and the record keeps M_SUSP.  k_shade shades the records whose ray is
-// finished and carries the suspended ones over unshaded; the next k_late resumes them.  A path that was set aside is
-// shaded a round later than its peers, which is why the bounce index travels with the record: every draw is still
-// addressed by (pixel, sample, path's own bounce, draw) and a path's radiance additions keep their order, so the image
-// is the same bits -- only the rounds get short (a launch ends after ~budget iterations instead of its longest ray).
-constexpr uint32_t M_SHADOW = 1u, M_ALIVE = 2u, M_SUSP = 4u, M_SLOT_SHIFT = 3u;  // mode: shadow ray pending, next ray pending (path
-                                                                                   // alive), walk set aside; state slot + 1 above
-
 struct PathArrays {      // the arrays one bounce works on (all indexed by POSITION unless noted)
     // 16-byte records; the w lanes carry the scalar path state, so a bounce moves 3 records per path
     // in and 3 out (the bounce number is the wavefront iteration: a kernel argument, not path state)
@@ -94,15 +79,8 @@ struct PathArrays {      // the arrays one bounce works on (all indexed by POSIT
     uint32_t* work;      // WORK_BUF_U32 (device_trace.h), zeroed by k_publish of every bounce: closest-hit launches (and the
                          // tail kernel) use the first NSEG counters, shadow launches the second NSEG, a mixed launch all of
                          // them (its 2 NSEG segments in order) -- each counter serves one launch per bounce
-    unsigned long long* tail;   // k_tail totals (see k_tail); [8] highest bounce index shaded in a late round, [9] walks set aside
+    unsigned long long* tail;   // k_tail totals (see k_tail)
     unsigned long long* visit; // [0] n_int extend, [1] n_tri extend, [2] n_int shadow, [3] n_tri shadow
-    // late rounds (records): in a late region sh_d / sh_c are indexed by POSITION like the rest of the record
-    uint32_t late_in, late_out;  // this bounce's paths are records / its survivors are written as records
-    uint32_t *pbounce, *npbounce;  // RNG bounce index of the path's next shade (null: the wavefront iteration, rp.bounce)
-    float4 *nsh_d, *nsh_c;       // the output region's shadow direction | mode bits, pending term
-    uint32_t* trav;              // state slots of walks set aside: trav_stride u32 each
-    uint32_t trav_stride, trav_cap;
-    uint32_t* trav_count;        // slots handed out so far in this batch
 };
 
 struct RenderParams {
@@ -238,7 +216,6 @@ RT_DEV TraceTune render_tune(const TuneBase& b, uint32_t n_total, uint32_t n_seg
     t.w_leaf = b.w_leaf;
     t.n_seg = n_seg;
     t.seg_len = seg_cap;
-    t.budget = 0xFFFFFFFFu;
     return t;
 }
 
@@ -280,21 +257,6 @@ RT_DEV void add_pending_nee(const PathArrays& pa, uint32_t i, uint32_t id) {  //
     r.y = add ? r.y + c.y : r.y;
     r.z = add ? r.z + c.z : r.z;
     pa.rad[id] = r;
-}
-
-// State slots of walks set aside (late rounds, M_SUSP): SAVED_WORDS of the traversal loop, the stack, and at the end of
-// the slot the best hit the walk had recorded (it goes back beside the record's position when the walk is resumed).
-constexpr uint32_t TRAV_POOLS = 64;     // slots are handed out from 64 pools (block index mod 64), one counter line each
-constexpr uint32_t TRAV_IO_WORDS = 8;   // hit_a (4), hit_b (2), 2 unused
-RT_DEV uint32_t* trav_slot(const PathArrays& pa, uint32_t slot1) { return pa.trav + (size_t)(slot1 - 1u) * pa.trav_stride; }
-RT_DEV const uint32_t* trav_resume(const PathArrays& pa, uint32_t i, uint32_t mode) {
-    const uint32_t* rec = trav_slot(pa, mode >> M_SLOT_SHIFT);
-    if ((mode & M_SHADOW) == 0u && (rec[SAVED_FLAGS] & 1u) != 0u) {
-        const uint32_t* h = rec + pa.trav_stride - TRAV_IO_WORDS;
-        pa.hit_a[i] = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3]));
-        pa.hit_b[i] = make_uint2(h[4], h[5]);
-    }
-    return rec;
 }
 
 struct ShadowIO {  // ray i = shadow record i; an unoccluded ray adds its pending NEE term
@@ -537,47 +499,19 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
 // every lane writes its records to its place: block offset + waves before + rank inside the wave's ballot.  Inside a
 // block the order of the paths is kept, between blocks it is the order the reservations arrive in -- close to the
 // launch order, so what was coherent stays so, and no bit of the image depends on it.
-// LATE_IN: the paths are records (late rounds): a record whose walk k_late set aside is carried over as it is, one whose
-// next ray is traced is shaded with the record's own bounce index.  LATE_OUT: what goes on is written as records --
-// one per path that is alive or has a shadow ray to trace -- and no separate shadow records.
-constexpr uint32_t QF_CARRY = 8u;  // a record carried over unshaded
-template <bool LATE_IN, bool LATE_OUT>
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa, RenderParams rp) {
-    static_assert(LATE_OUT || !LATE_IN, "records stay records");
     __shared__ uint32_t wave_cnt[3][SHADE_BLOCK / 64];
-    __shared__ uint32_t wave_max[SHADE_BLOCK / 64];
     __shared__ uint32_t base[2];
     const uint32_t seg = blockIdx.x % pa.ns, first = (blockIdx.x / pa.ns) * SHADE_BLOCK;
     const uint32_t n = pa.cnt[CNT_ALIVE + seg];
     if (first >= n) return;  // the grid is sized from an upper bound of the fullest segment (uniform per block)
     const uint32_t local = first + threadIdx.x, seg0 = seg * pa.seg_stride;
     const uint32_t oseg = seg / (pa.ns / pa.ns_out), oseg0 = oseg * pa.out_stride;  // where this segment's survivors go
-    uint32_t flags = 0, bounce = rp.bounce;
-    bool shaded = false;
+    uint32_t flags = 0;
     ShadeOut out;
-    if constexpr (LATE_OUT) {  // every field of a record is written, whatever shade_path filled in
-        out.d4 = out.b4 = out.sh_d = out.sh_c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    if (local < n) {
-        const uint32_t slot = seg0 + local;
-        if constexpr (LATE_IN) {
-            const float4 s4 = pa.sh_d[slot];
-            const uint32_t mode = __float_as_uint(s4.w);
-            bounce = pa.pbounce[slot];
-            if (mode & M_SUSP) {
-                flags = QF_CARRY;  // copied from position to position below
-            } else if (mode & M_ALIVE) {
-                flags = shade_path(sc, pa, rp, slot, bounce, out);
-                shaded = true;
-            }  // else: the record of a path that had ended, its shadow ray is traced: nothing is left of it
-        } else {
-            flags = shade_path(sc, pa, rp, slot, bounce, out);
-        }
-    }
-    const bool goes_on = LATE_OUT ? (flags & (QF_ALIVE | QF_SHADOW | QF_CARRY)) != 0 : (flags & QF_ALIVE) != 0;
-    const bool to_shadow = !LATE_OUT && (flags & QF_SHADOW) != 0;
-    const unsigned long long alive = __ballot(goes_on);
-    const unsigned long long shadow = __ballot(to_shadow);
+    if (local < n) flags = shade_path(sc, pa, rp, seg0 + local, rp.bounce, out);
+    const unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
+    const unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
     const unsigned long long skipped = __ballot((flags & QF_SKIPPED) != 0);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
@@ -585,21 +519,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
         wave_cnt[1][wave] = (uint32_t)__popcll(shadow);
         wave_cnt[2][wave] = (uint32_t)__popcll(skipped);
     }
-    if constexpr (LATE_IN) {  // rt_stats::iterations: the highest bounce index any path was shaded at
-        uint32_t mb = shaded ? bounce : 0u;
-        for (int off = 32; off > 0; off >>= 1) mb = max(mb, (uint32_t)__shfl_down((int)mb, off));
-        if (lane == 0) wave_max[wave] = mb;
-    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t[3] = {0, 0, 0};
         for (int w = 0; w < SHADE_BLOCK / 64; ++w)
             for (int q = 0; q < 3; ++q) t[q] += wave_cnt[q][w];
-        if constexpr (LATE_IN) {  // one look at the maximum so far (any stale value only costs an atomic), one atomic if this block raises it
-            uint32_t mb = 0;
-            for (int w = 0; w < SHADE_BLOCK / 64; ++w) mb = max(mb, wave_max[w]);
-            if (mb > (uint32_t)__hip_atomic_load(&pa.tail[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&pa.tail[8], (unsigned long long)mb);
-        }
         unsigned long long r = 0ull;
         if (t[0] | t[1]) r = atomicAdd(&pa.acc[oseg * ACC_STRIDE], (unsigned long long)t[0] | ((unsigned long long)t[1] << 32));
         base[0] = (uint32_t)r;
@@ -608,36 +532,15 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     }
     __syncthreads();
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    if (goes_on) {
+    if (flags & QF_ALIVE) {
         uint32_t pos = oseg0 + base[0] + (uint32_t)__popcll(alive & below);
         for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[0][w];
-        if (LATE_IN && (flags & QF_CARRY)) {  // a walk set aside: the record as it is (its mode names the state slot)
-            const uint32_t slot = seg0 + local;
-            pa.nray_o[pos] = pa.ray_o[slot];
-            pa.nray_d[pos] = pa.ray_d[slot];
-            pa.nbeta[pos] = pa.beta[slot];
-            pa.noid[pos] = pa.oid[slot];
-            pa.npbounce[pos] = bounce;
-            pa.nsh_d[pos] = pa.sh_d[slot];
-            pa.nsh_c[pos] = pa.sh_c[slot];
-        } else if constexpr (LATE_OUT) {
-            const bool live = (flags & QF_ALIVE) != 0, sh = (flags & QF_SHADOW) != 0;
-            pa.nray_o[pos] = out.o4;
-            pa.noid[pos] = out.id;
-            pa.nray_d[pos] = out.d4;
-            pa.nbeta[pos] = out.b4;
-            pa.npbounce[pos] = bounce + 1u;
-            const uint32_t mode = (sh ? M_SHADOW : 0u) | (live ? M_ALIVE : 0u);
-            pa.nsh_d[pos] = make_float4(out.sh_d.x, out.sh_d.y, out.sh_d.z, __uint_as_float(mode));
-            pa.nsh_c[pos] = out.sh_c;
-        } else {
-            pa.nray_o[pos] = out.o4;
-            pa.noid[pos] = out.id;
-            pa.nray_d[pos] = out.d4;
-            pa.nbeta[pos] = out.b4;
-        }
+        pa.nray_o[pos] = out.o4;
+        pa.nray_d[pos] = out.d4;
+        pa.nbeta[pos] = out.b4;
+        pa.noid[pos] = out.id;
     }
-    if (to_shadow) {
+    if (flags & QF_SHADOW) {
         uint32_t pos = oseg0 + base[1] + (uint32_t)__popcll(shadow & below);
         for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[1][w];
         pa.sh_o[pos] = make_float4(out.o4.x, out.o4.y, out.o4.z, __uint_as_float(out.id));
@@ -682,7 +585,7 @@ __global__ __launch_bounds__(64) void k_publish(PathArrays pa, uint32_t* cnt_out
 
 // ---------------------------------------------------------------- tail
 // A frame of a few thousand paths spends its time in launches and host round trips (5 launches and a
-// sync per bounce).  When no more than RT_TAIL_PATHS (default 32 768) paths are alive, k_tail runs each
+// sync per bounce).  When no more than RT_TAIL_PATHS (default 131 072) paths are alive, k_tail runs each
 // of them to its end inside ONE persistent launch: a lane traces the path's ray, shades the vertex when
 // the ray finishes (the same shade_path), traces the shadow ray if one was produced, adds the pending
 // light term if it is unoccluded, and goes on with the next bounce.  Per path the order of operations
@@ -692,8 +595,7 @@ __global__ __launch_bounds__(64) void k_publish(PathArrays pa, uint32_t* cnt_out
 // (hundreds of dependent fetches, ~0.35 ms) in either scheme, and with shading inside the traversal loop
 // each iteration costs more -- 219 000 paths took 4.0 ms here against 4.3 ms as five wavefront rounds
 // (profiles/r01/tuning.md), hence the low threshold.
-template <bool REC>  // REC: the paths are the RECORDS of a late region (pending shadow rays, walks set aside, own bounce index)
-struct TailIOT {
+struct TailIO {
     PathArrays pa;      // the region the paths are in; their state is updated IN PLACE (nothing is compacted here)
     const DScene* sc;
     const RenderParams* rp;
@@ -702,37 +604,13 @@ struct TailIOT {
     unsigned long long n_int_sh, n_tri_sh;             // shadow visits (COUNT)
     bool alive_after;                                  // the path goes on after its pending shadow ray
     uint32_t id;                                       // original slot of the lane's path
-    uint32_t bounce0;                                  // RNG bounce index of the path's first shade in this launch
-    uint32_t mode;                                     // REC: the record's mode word
-    RT_DEV void started_closest() {
-        n_closest += 1;
-        iters += 1;
-        if (!REC && iters > max_iters) max_iters = iters;
-    }
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) {
         float4 o4 = pa.ray_o[i], d4 = pa.ray_d[i];
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
-        iters = 0;
-        bounce0 = rp->bounce;
-        mode = M_ALIVE;
-        if constexpr (REC) {
-            const float4 s4 = pa.sh_d[i];
-            mode = __float_as_uint(s4.w);
-            bounce0 = pa.pbounce[i];
-            if (mode & M_SHADOW) {  // the record's shadow ray first; next() goes on to its next ray if the path is alive
-                *d = v3(s4.x, s4.y, s4.z);
-                id = pa.oid[i];
-                alive_after = (mode & M_ALIVE) != 0u;
-                if ((mode & M_SUSP) == 0u) n_shadow += 1;
-                return i;
-            }
-            if (mode & M_SUSP) {  // a next-ray walk an earlier launch had started (and counted)
-                iters = 1;
-                return i;
-            }
-        }
-        started_closest();
+        n_closest += 1;
+        iters = 1;
+        if (iters > max_iters) max_iters = iters;
         return i;
     }
     static constexpr bool DEFER_NORMAL = true;
@@ -741,10 +619,7 @@ struct TailIOT {
         pa.hit_b[i] = make_uint2(meta, tri);
     }
     static constexpr bool CONTINUES = true;  // next() carries the lane on to the path's shadow ray / next bounce
-    static constexpr bool CHAINS = false, SUSPENDS = REC;  // REC: walks set aside by k_late are resumed here, none is set aside
-    RT_DEV bool first_is_any(uint32_t) const { return REC && (mode & M_SHADOW) != 0u; }
-    RT_DEV const uint32_t* resumes(uint32_t i) const { return (REC && (mode & M_SUSP) != 0u) ? trav_resume(pa, i, mode) : nullptr; }
-    RT_DEV uint32_t* suspend(uint32_t, bool, bool, const uint32_t (&)[SAVED_WORDS]) { return nullptr; }
+    RT_DEV bool first_is_any(uint32_t) const { return false; }
     RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
         pa.hit_a[i] = make_float4(t, n.x, n.y, n.z);
         pa.hit_b[i] = make_uint2(meta, prim);
@@ -756,7 +631,9 @@ struct TailIOT {
         *o = v3(o4.x, o4.y, o4.z);
         *d = v3(d4.x, d4.y, d4.z);
         *any = false;
-        started_closest();
+        n_closest += 1;
+        iters += 1;
+        if (iters > max_iters) max_iters = iters;
         return true;
     }
     RT_DEV bool next(uint32_t i, bool was_any, bool got, bool occluded, const Visits& vis, V3* o, V3* d, bool* any) {
@@ -765,9 +642,7 @@ struct TailIOT {
             n_tri += vis.n_tri;
             if (!got) pa.hit_b[i] = make_uint2(RT_MISS, RT_MISS);
             ShadeOut out;
-            const uint32_t bounce = bounce0 + iters - 1u;
-            if (REC && bounce > max_iters) max_iters = bounce;  // REC: the highest bounce index shaded (paths start at different ones)
-            const uint32_t flags = shade_path(*sc, pa, *rp, i, bounce, out);
+            const uint32_t flags = shade_path(*sc, pa, *rp, i, rp->bounce + iters - 1u, out);
             id = out.id;
             alive_after = (flags & QF_ALIVE) != 0;
             if (flags & QF_SKIPPED) n_skipped += 1;
@@ -792,7 +667,6 @@ struct TailIOT {
         return alive_after ? next_bounce(i, o, d, any) : false;
     }
 };
-typedef TailIOT<false> TailIO;
 
 RT_DEV unsigned long long wave_sum_u64(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -807,7 +681,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, Ren
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n = pa.cnt[CNT_TOT_ALIVE];
     const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
-    TailIO io{pa, &sc, &rp, 0u, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false, 0u, 0u, 0u};
+    TailIO io{pa, &sc, &rp, 0u, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false, 0u};
     trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
                                                           lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_ALIVE);
     unsigned long long v[6] = {io.n_closest, io.n_shadow, io.n_int, io.n_tri, io.n_int_sh, io.n_tri_sh};
@@ -820,31 +694,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, Ren
             if (v[k]) atomicAdd(&pa.tail[k], v[k]);
         atomicMax(&pa.tail[6], (unsigned long long)mx);
         if (sk) atomicAdd(&pa.tail[7], sk);
-    }
-}
-
-// The same for the RECORDS of a late region: a record's pending shadow ray comes first, a walk k_late set aside goes on
-// where it stopped, every path is shaded with its own bounce index (pa.tail[8]: the highest one).
-#ifndef RT_WAVES_EU_TAIL_REC
-#define RT_WAVES_EU_TAIL_REC 2
-#endif
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_TAIL_REC))) void k_tail_rec(DScene sc, PathArrays pa, RenderParams rp, TuneBase base, uint32_t* overflow,
-                                                       uint32_t overflow_stride) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t n = pa.cnt[CNT_TOT_ALIVE];
-    const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
-    TailIOT<true> io{pa, &sc, &rp, 0u, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false, 0u, 0u, 0u};
-    trace_loop<TRACE_PATH, COUNT_NONE, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
-                                                               lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_ALIVE);
-    uint32_t mx = io.max_iters;
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
-    const unsigned long long c = wave_sum_u64(io.n_closest), sh = wave_sum_u64(io.n_shadow), sk = wave_sum_u64(io.n_skipped);
-    if ((threadIdx.x & 63) == 0) {
-        if (c) atomicAdd(&pa.tail[0], c);
-        if (sh) atomicAdd(&pa.tail[1], sh);
-        if (sk) atomicAdd(&pa.tail[7], sk);
-        if (mx) atomicMax(&pa.tail[8], (unsigned long long)mx);
     }
 }
 
@@ -862,7 +711,6 @@ struct MixedIO {
     uint32_t n_shadow_items;  // NSEG * seg_cap: items below it are shadow records, item i at or above it is position i - n_shadow_items
     unsigned long long n_int, n_tri, n_int_sh, n_tri_sh;
     static constexpr bool CONTINUES = false;  // a finished ray is finished: the lane takes a new one
-    static constexpr bool CHAINS = false, SUSPENDS = false;
     RT_DEV bool first_is_any(uint32_t i) const { return i < n_shadow_items; }
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // the tag is the item
         const bool sh = i < n_shadow_items;
@@ -929,122 +777,6 @@ __global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays pa, TuneBa
     MixedIO io{pa, pa.n_positions, 0ull, 0ull, 0ull, 0ull};
     trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
         sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_MIXED);
-}
-
-// ---------------------------------------------------------------- late rounds (see M_SHADOW above)
-struct LateIO {  // item i = the record at position i of a late region
-    PathArrays pa;
-    uint32_t mode;      // per lane: mode of the lane's record (phase bits as the walk stands, slot + 1 once it has one)
-    uint32_t loaded;    // per lane: the mode word as it stands in memory
-    uint32_t n_closest, n_shadow, n_suspended;  // per lane: rays STARTED by this lane; walks it set aside
-    static constexpr bool CONTINUES = false;  // nothing is parked ...
-    static constexpr bool CHAINS = true;      // ... the record's next ray follows its shadow ray at once
-    static constexpr bool SUSPENDS = true;
-    static constexpr bool DEFER_NORMAL = true;
-    RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) {
-        const float4 o4 = pa.ray_o[i], s4 = pa.sh_d[i], d4 = pa.ray_d[i];
-        mode = loaded = __float_as_uint(s4.w);
-        *o = v3(o4.x, o4.y, o4.z);
-        const bool sh = (mode & M_SHADOW) != 0u, fresh_walk = (mode & M_SUSP) == 0u;
-        *d = sh ? v3(s4.x, s4.y, s4.z) : v3(d4.x, d4.y, d4.z);
-        if (fresh_walk) {
-            if (sh) n_shadow += 1;
-            else n_closest += 1;
-        }
-        return i;
-    }
-    RT_DEV bool first_is_any(uint32_t) const { return (mode & M_SHADOW) != 0u; }
-    RT_DEV const uint32_t* resumes(uint32_t i) {
-        if ((mode & M_SUSP) == 0u) return nullptr;
-        const uint32_t* rec = trav_resume(pa, i, mode);
-        mode &= ~M_SUSP;
-        return rec;
-    }
-    // Called by the lanes of a wave that are over the budget (divergent).  Lanes whose record has no slot yet take
-    // consecutive slots of the block's pool with one atomic between them.
-    RT_DEV uint32_t* suspend(uint32_t i, bool lane_any, bool got, const uint32_t (&saved)[SAVED_WORDS]) {
-        uint32_t slot1 = mode >> M_SLOT_SHIFT;
-        const bool need = slot1 == 0u;
-        const unsigned long long nm = __ballot(need);
-        if (need) {
-            const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(nm);
-            const uint32_t pool = blockIdx.x % TRAV_POOLS, pool_cap = pa.trav_cap / TRAV_POOLS;
-            uint32_t first = 0;
-            if (lane == leader) first = atomicAdd(pa.trav_count + pool * 32u, (uint32_t)__popcll(nm));
-            first = (uint32_t)__shfl((int)first, (int)leader);
-            const uint32_t mine = first + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
-            if (mine >= pool_cap) return nullptr;  // pool exhausted: the lane keeps its ray and walks on
-            slot1 = pool * pool_cap + mine + 1u;
-        }
-        uint32_t* rec = trav_slot(pa, slot1);
-        for (uint32_t w = 0; w < SAVED_WORDS; ++w) rec[w] = saved[w];
-        if (!lane_any && got) {
-            const float4 a = pa.hit_a[i];
-            const uint2 b = pa.hit_b[i];
-            uint32_t* h = rec + pa.trav_stride - TRAV_IO_WORDS;
-            h[0] = __float_as_uint(a.x), h[1] = __float_as_uint(a.y), h[2] = __float_as_uint(a.z), h[3] = __float_as_uint(a.w);
-            h[4] = b.x, h[5] = b.y;
-        }
-        mode = (mode & (M_SHADOW | M_ALIVE)) | M_SUSP | (slot1 << M_SLOT_SHIFT);
-        ((uint32_t*)&pa.sh_d[i])[3] = mode;
-        n_suspended += 1;
-        return rec;
-    }
-    RT_DEV void hit_mesh(uint32_t i, float t, uint32_t meta, uint32_t tri) const {
-        ((float*)&pa.hit_a[i])[0] = t;
-        pa.hit_b[i] = make_uint2(meta, tri);
-    }
-    RT_DEV void hit(uint32_t i, float t, V3 n, uint32_t meta, uint32_t prim) const {
-        pa.hit_a[i] = make_float4(t, n.x, n.y, n.z);
-        pa.hit_b[i] = make_uint2(meta, prim);
-    }
-    RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
-    RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
-    RT_DEV bool next(uint32_t i, bool was_any, bool got, bool occluded, const Visits&, V3*, V3* d, bool* any) {
-        if (was_any) {  // the shadow ray: its term joins the radiance now, ahead of anything the path's next shade adds
-            if (!occluded) add_pending_nee(pa, i, pa.oid[i]);
-            if (mode & M_ALIVE) {  // the path's next ray starts at the same vertex
-                const float4 d4 = pa.ray_d[i];
-                *d = v3(d4.x, d4.y, d4.z);
-                *any = false;
-                mode &= ~(M_SHADOW | M_SUSP);
-                n_closest += 1;
-                return true;
-            }
-            ((uint32_t*)&pa.sh_d[i])[3] = 0u;  // the path had ended: nothing is left of the record
-            return false;
-        }
-        if (!got) pa.hit_b[i] = make_uint2(RT_MISS, RT_MISS);
-        if (loaded != M_ALIVE) ((uint32_t*)&pa.sh_d[i])[3] = M_ALIVE;  // traced: k_shade shades the path
-        return false;
-    }
-};
-
-template <int STACK, uint32_t FEAT, bool OVERFLOW>
-RT_DEV void late_body(const DScene& sc, const PathArrays& pa, const TuneBase& base, uint32_t budget, uint32_t* lds_stack,
-                      uint32_t* overflow, uint32_t overflow_stride) {
-    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t n = pa.cnt[CNT_TOT_ALIVE];
-    TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
-    tune.budget = budget;
-    LateIO io{pa, 0u, 0u, 0u, 0u, 0u};
-    trace_loop<TRACE_PATH, COUNT_NONE, STACK, RT_BLOCK, FEAT, OVERFLOW>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
-                                                                        lds_stack + threadIdx.x, overflow + gtid, overflow_stride,
-                                                                        pa.cnt + CNT_ALIVE);
-    const unsigned long long c = wave_sum_u64(io.n_closest), sh = wave_sum_u64(io.n_shadow), su = wave_sum_u64(io.n_suspended);
-    if ((threadIdx.x & 63) == 0) {
-        if (c) atomicAdd(&pa.tail[0], c);
-        if (sh) atomicAdd(&pa.tail[1], sh);
-        if (su) atomicAdd(&pa.tail[9], su);
-    }
-}
-__global__ RT_TRACE_ATTR void k_late(DScene sc, PathArrays pa, TuneBase base, uint32_t budget, uint32_t* overflow, uint32_t overflow_stride) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    late_body<RT_STACK_LDS, FEAT_ALL, true>(sc, pa, base, budget, lds_stack, overflow, overflow_stride);
-}
-__global__ RT_TRACE_ATTR void k_late_lean(DScene sc, PathArrays pa, TuneBase base, uint32_t budget, uint32_t* overflow, uint32_t overflow_stride) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    late_body<RT_STACK_LDS, RT_LEAN_FEAT, true>(sc, pa, base, budget, lds_stack, overflow, overflow_stride);
 }
 
 // ---------------------------------------------------------------- resolve
@@ -1190,26 +922,8 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         ro[r].ray_o = carve(Ppos * 16), ro[r].ray_d = carve(Ppos * 16), ro[r].beta = carve(Ppos * 16), ro[r].oid = carve(Ppos * 4);
     const size_t o_hit_a = carve(Ppos * 16), o_hit_b = carve(Ppos * 8), o_sh_o = carve(Ppos * 16), o_sh_d = carve(Ppos * 16),
                  o_sh_c = carve(Ppos * 16), o_rad = carve(P * 16);
-    // late rounds (see M_SHADOW): two record regions of LC positions (the hit records are the big ones: positions < LC <= Ppos)
-    // and the state slots of the walks set aside
-    static const uint64_t late_cap_max = [] {  // RT_LATE_CAP: positions of a late region
-        const char* e = getenv("RT_LATE_CAP");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)8 << 20;
-    }();
-    const uint32_t seg_cap_late = (uint32_t)std::min<uint64_t>(seg_cap, ((late_cap_max + NSEG - 1) / NSEG + SHADE_BLOCK - 1) / SHADE_BLOCK * SHADE_BLOCK);
-    const uint64_t LC = (uint64_t)seg_cap_late * NSEG;
-    struct LateOff {
-        size_t ray_o, ray_d, beta, oid, pbounce, sh_d, sh_c;
-    } lo[2];
-    for (int r = 0; r < 2; ++r)
-        lo[r].ray_o = carve(LC * 16), lo[r].ray_d = carve(LC * 16), lo[r].beta = carve(LC * 16), lo[r].oid = carve(LC * 4),
-        lo[r].pbounce = carve(LC * 4), lo[r].sh_d = carve(LC * 16), lo[r].sh_c = carve(LC * 16);
-    const uint32_t trav_stride = (rtd::SAVED_WORDS + ctx->scene.stack_need + 1u + TRAV_IO_WORDS + 3u) & ~3u;
-    const uint32_t trav_cap = (uint32_t)(std::min<uint64_t>(LC, (uint64_t)2 << 20) / TRAV_POOLS * TRAV_POOLS);
-    const size_t o_trav = carve((size_t)trav_cap * trav_stride * 4);
-    // small state, zeroed together at the start of every batch: accumulators, skipped total, work counters, slot counters
-    const size_t o_acc = carve((size_t)NSEG * ACC_STRIDE * 8), o_skip = carve(256), o_work = carve(rtd::WORK_BUF_U32 * 4),
-                 o_trav_count = carve((size_t)TRAV_POOLS * 32 * 4);
+    // small state, zeroed together at the start of every batch: accumulators, skipped total, work counters
+    const size_t o_acc = carve((size_t)NSEG * ACC_STRIDE * 8), o_skip = carve(256), o_work = carve(rtd::WORK_BUF_U32 * 4);
     const size_t zero_bytes = off - o_acc;
     const size_t o_cnt = carve(2 * CNT_U32 * 4), o_vis = carve(256), o_tail = carve(256);
     int rc = ctx->path_state.ensure(off);
@@ -1221,7 +935,6 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     // segments per bounce (see NSEG above): what a launch of that many rays wants; never growing over the bounces.
     // ns_of[k + 1] has to be known when bounce k is shaded, i.e. from bounds the host has then.
     std::vector<uint32_t> ns_of;
-    std::vector<uint8_t> late;  // late[k]: the paths of bounce k are records in a late region (decided before bounce k - 1 is shaded)
     auto segments_for = [](uint64_t n) {
         uint32_t ns = 1;
         while (ns < NSEG && (uint64_t)ns * 2u * 131072u <= n) ns *= 2;
@@ -1249,44 +962,15 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         q.acc_skipped = (uint32_t*)(base + o_skip);
         q.n_positions = (uint32_t)Ppos;
         q.ns = ns_of[k];
+        q.seg_stride = seg_cap * (NSEG / q.ns);
         q.ns_out = ns_of[k + 1];
-        q.late_in = late[k];
-        q.late_out = late[k + 1];
-        q.seg_stride = (q.late_in ? seg_cap_late : seg_cap) * (NSEG / q.ns);
-        q.out_stride = (q.late_out ? seg_cap_late : seg_cap) * (NSEG / q.ns_out);
-        q.pbounce = q.npbounce = nullptr;
-        q.nsh_d = q.nsh_c = nullptr;
-        if (q.late_in) {  // the record's fields, all indexed by position
-            const LateOff& li = lo[k & 1];
-            q.ray_o = (float4*)(base + li.ray_o);
-            q.ray_d = (float4*)(base + li.ray_d);
-            q.beta = (float4*)(base + li.beta);
-            q.oid = (uint32_t*)(base + li.oid);
-            q.pbounce = (uint32_t*)(base + li.pbounce);
-            q.sh_d = (float4*)(base + li.sh_d);
-            q.sh_c = (float4*)(base + li.sh_c);
-        }
-        if (q.late_out) {
-            const LateOff& ln = lo[(k + 1) & 1];
-            q.nray_o = (float4*)(base + ln.ray_o);
-            q.nray_d = (float4*)(base + ln.ray_d);
-            q.nbeta = (float4*)(base + ln.beta);
-            q.noid = (uint32_t*)(base + ln.oid);
-            q.npbounce = (uint32_t*)(base + ln.pbounce);
-            q.nsh_d = (float4*)(base + ln.sh_d);
-            q.nsh_c = (float4*)(base + ln.sh_c);
-        }
-        q.trav = (uint32_t*)(base + o_trav);
-        q.trav_stride = trav_stride;
-        q.trav_cap = trav_cap;
-        q.trav_count = (uint32_t*)(base + o_trav_count);
+        q.out_stride = seg_cap * (NSEG / q.ns_out);
         q.work = (uint32_t*)(base + o_work);
         q.visit = (unsigned long long*)(base + o_vis);
         q.tail = (unsigned long long*)(base + o_tail);
         return q;
     };
     ns_of.assign(2, NSEG);
-    late.assign(2, 0);
     const PathArrays pa = view(0);  // what does not depend on the bounce: rad, work, visit, tail
     RT_HIP(hipMemsetAsync(pa.visit, 0, 256, stream));
     RT_HIP(hipMemsetAsync(pa.tail, 0, 256, stream));
@@ -1318,48 +1002,12 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     const bool lean = rt_scene_is_lean(ctx) && getenv("RT_NO_LEAN") == nullptr;
     static const uint32_t tail_paths = [] {  // RT_TAIL_PATHS overrides the switch-over point (experiments)
         const char* e = getenv("RT_TAIL_PATHS");
-        return e ? (uint32_t)strtoul(e, nullptr, 10) : 32768u;
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : 131072u;  // profiles/r03/tuning.md section 4
     }();
     static const uint32_t async_below = [] {  // RT_ASYNC_BELOW: bounces with at most this many paths are enqueued
         const char* e = getenv("RT_ASYNC_BELOW");  // without waiting for their exact counts (0: always wait)
         return e ? (uint32_t)strtoul(e, nullptr, 10) : (16u << 20);
     }();
-    // Late rounds (records, budgeted launches: see M_SHADOW).  RT_LATE_PATHS: paths from which on a bounce's survivors are
-    // written as records (0: never); RT_LATE_BUDGET: wave iterations a lane may spend on a record per launch;
-    // RT_TAIL_PATHS_LATE: records from which on the tail kernel takes them to their end (budgeted rounds are cheap: it
-    // is only for the few long paths of a medium, whose every bounce would otherwise be a round of three launches).
-    static const uint32_t late_paths_env = [] {
-        const char* e = getenv("RT_LATE_PATHS");
-        return e ? (uint32_t)strtoul(e, nullptr, 10) : (4u << 20);
-    }();
-    static const uint32_t late_budget_env = [] {
-        const char* e = getenv("RT_LATE_BUDGET");
-        return e ? (uint32_t)strtoul(e, nullptr, 10) : 64u;
-    }();
-    static const uint32_t tail_paths_late_env = [] {
-        const char* e = getenv("RT_TAIL_PATHS_LATE");
-        return e ? (uint32_t)strtoul(e, nullptr, 10) : 4096u;
-    }();
-    static const bool late_tail_at_end = [] {
-        const char* e = getenv("RT_LATE_TAIL_AT_END");
-        return e ? atoi(e) != 0 : true;
-    }();
-    // RT_RENDER_LATE_STRESS / _STRESS2 (tests): records from the first bounce on, a budget of three iterations -- nearly
-    // every walk is set aside, most of them several times -- and the tail kernel only for the last 64 records / for
-    // whatever is left after two late rounds (records with pending shadow rays and walks set aside).
-    const bool stress = (flags & (RT_RENDER_LATE_STRESS | RT_RENDER_LATE_STRESS2)) != 0, stress2 = (flags & RT_RENDER_LATE_STRESS2) != 0;
-    const bool use_late = use_mix && count == rtd::COUNT_NONE && (stress || late_paths_env > 0);
-    const uint32_t late_paths = stress ? 0xFFFFFFFFu : late_paths_env;
-    const uint32_t late_budget = stress ? 3u : late_budget_env;
-    const uint32_t tail_paths_big = (stress && use_late) ? 0u : tail_paths;  // threshold while the paths are not records
-    auto tail_threshold = [&](size_t k) -> uint32_t {  // ... and for bounce k, whose paths are late[k] ? records : not
-        if (!late[k]) return tail_paths_big;
-        if (stress2) return k >= 3 ? 0xFFFFFFFFu : 0u;
-        if (stress) return 64u;
-        // past the round in which the paths that were never set aside have ended, what is left are the paths that fell
-        // behind: one launch to their end instead of a round of three launches per bounce
-        return (k >= depth && late_tail_at_end) ? 0xFFFFFFFFu : tail_paths_late_env;
-    };
     const bool timing = (flags & RT_RENDER_TIME_STAGES) != 0;
     // HIP events on the library's stream around every launch of a stage, summed per stage after the frame's last
     // synchronisation (the host runs ahead of the device, so a span cannot be read back where it is recorded).
@@ -1454,24 +1102,8 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         else
             hipLaunchKernelGGL(k_mixed<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, overflow, ostride);
     };
-    auto launch_late = [&](int grid, const PathArrays& q) {
-        if (lean)
-            hipLaunchKernelGGL(k_late_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, late_budget, overflow, ostride);
-        else
-            hipLaunchKernelGGL(k_late, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, tune, late_budget, overflow, ostride);
-    };
-    auto launch_shade = [&](uint32_t grid, const PathArrays& q) {
-        if (q.late_in)
-            hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(SHADE_BLOCK), 0, stream, ctx->scene, q, rp);
-        else if (q.late_out)
-            hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(SHADE_BLOCK), 0, stream, ctx->scene, q, rp);
-        else
-            hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(SHADE_BLOCK), 0, stream, ctx->scene, q, rp);
-    };
     auto launch_tail = [&](int grid, const PathArrays& q) {
-        if (q.late_in)
-            hipLaunchKernelGGL(k_tail_rec, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, tune, overflow, ostride);
-        else if (count == rtd::COUNT_REFERENCE)
+        if (count == rtd::COUNT_REFERENCE)
             hipLaunchKernelGGL(k_tail<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
             hipLaunchKernelGGL(k_tail<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, tune, overflow, ostride);
@@ -1482,7 +1114,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     // What the host remembers of a bounce: which launches it enqueued, and the counts k_publish wrote for it
     // (read from pinned memory once the event recorded behind that kernel has completed).
     struct Bounce {
-        bool extend = false, mixed = false, shadow = false, late = false, got = false;
+        bool extend = false, mixed = false, shadow = false, got = false;
         uint32_t n_next = 0, n_shadow = 0, n_skipped = 0;  // paths alive after the bounce, its shadow rays traced / not needed
         uint32_t seg_max = 0;                              // survivors in the fullest segment
     };
@@ -1508,7 +1140,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         rp.s_count = s_count;
         // first-bounce state implicit unless the tail kernel takes the batch from its first bounce (it reads
         // every path's state from memory)
-        const bool implicit = !user_rays && depth > 0 && !(use_tail && n_paths <= tail_paths_big) && getenv("RT_NO_IMPLICIT") == nullptr;
+        const bool implicit = !user_rays && depth > 0 && !(use_tail && n_paths <= tail_paths) && getenv("RT_NO_IMPLICIT") == nullptr;
         rp.implicit_first = implicit ? 1u : 0u;
         rp.bounce = 0u;
         // ---- the wavefront loop.  n_ub is an UPPER BOUND of the paths alive at bounce k (seg_ub: in its fullest
@@ -1521,7 +1153,6 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         hist.clear();
         uint32_t n_ub = depth > 0 ? n_paths : 0;
         ns_of.assign(2, segments_for(n_paths));
-        late.assign(3, 0);
         uint32_t seg_ub = std::min<uint64_t>(n_ub, (uint64_t)seg_cap * (NSEG / ns_of[0]));
         RT_HIP(hipMemsetAsync(base + o_acc, 0, zero_bytes, stream));  // accumulators, skipped total, work counters
         if ((rc = t_begin(0)) != RT_OK) return rc;
@@ -1541,20 +1172,11 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
             // the survivors of this bounce are at most n_ub: that picks the next bounce's segments
             if (ns_of.size() < k + 2) ns_of.resize(k + 2);
             ns_of[k + 1] = std::min(ns_of[k], segments_for(n_ub));
-            // Records from here on?  Decided before this bounce is shaded: what goes on is at most its n_ub paths, and the
-            // source segments a late segment merges must fit it (paths only die and every record gives at most one
-            // record, so what fits once fits ever after).
-            if (late.size() < k + 3) late.resize(k + 3, 0);
-            bool late_out = late[k] != 0;
-            if (!late_out && use_late && n_ub <= late_paths &&
-                (uint64_t)seg_ub * (ns_of[k] / ns_of[k + 1]) <= (uint64_t)seg_cap_late * (NSEG / ns_of[k + 1]))
-                late_out = true;
-            late[k + 1] = late[k + 2] = late_out ? 1 : 0;
             const PathArrays pr = view(k);
             rp.bounce = (uint32_t)k + 1;  // iteration k of `while depth > 0` draws from RNG bounce k+1 (bounce 0: camera jitter)
             const uint32_t first_implicit = (implicit && k == 0) ? 1u : 0u;
             rp.implicit_first = first_implicit;
-            if (use_tail && n_ub <= tail_threshold(k)) {  // few paths left: one launch takes them to their end
+            if (use_tail && n_ub <= tail_paths) {  // few paths left: one launch takes them to their end
                 RT_HIP(hipMemsetAsync(pa.tail + 6, 0, 8, stream));
                 if ((rc = t_begin(5)) != RT_OK) return rc;
                 launch_tail(rt_trace_grid(n_ub), pr);
@@ -1568,7 +1190,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
                     st.paths_tail += n_exact;
                     st.launches_tail += 1;
                 }
-                tail_iters_total = late[k] ? 0u : (uint32_t)tail_iters;  // records: the highest bounce index is in pa.tail[8]
+                tail_iters_total = (uint32_t)tail_iters;
                 break;
             }
             hist.emplace_back();
@@ -1583,7 +1205,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
             // shade + compaction: NSEG interleaved segments, grid sized from the fullest one
             const uint32_t seg_blocks = (seg_ub + SHADE_BLOCK - 1) / SHADE_BLOCK;
             if ((rc = t_begin(2)) != RT_OK) return rc;
-            launch_shade(seg_blocks * pr.ns, pr);
+            hipLaunchKernelGGL(k_shade, dim3(seg_blocks * pr.ns), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pr, rp);
             if ((rc = t_end(2)) != RT_OK) return rc;
             if (ns_of.size() < k + 3) ns_of.resize(k + 3, ns_of[k + 1]);
             ns_of[k + 2] = ns_of[k + 1];  // placeholder until bounce k + 1 decides it (view(k + 1) only uses it for its own shade)
@@ -1611,17 +1233,8 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
                 ng_ub = (uint32_t)std::min<uint64_t>(nn_ub, (uint64_t)(k > 0 ? std::min(seg_ub, hist[k - 1].seg_max) : seg_ub) * (ns_of[k] / ns_of[k + 1]));
             }
 
-            const bool tail_next = use_tail && nn_ub <= tail_threshold(k + 1);  // the tail kernel traces its own first ray
-            if (late_out) {  // records: their shadow rays and next rays in one budgeted launch (the tail kernel does the same itself)
-                ns_ub = 0;
-                if (nn_ub > 0 && !tail_next) {
-                    if ((rc = t_begin(5)) != RT_OK) return rc;
-                    launch_late(rt_trace_grid(nn_ub), pn);
-                    if ((rc = t_end(5)) != RT_OK) return rc;
-                    hist[k].late = true;
-                    extend_done = true;
-                }
-            } else if (use_mix && ns_ub > 0 && nn_ub > 0 && !tail_next && (uint64_t)ns_ub + nn_ub <= mix_paths) {
+            const bool tail_next = use_tail && nn_ub <= tail_paths;  // the tail kernel traces its own first ray
+            if (use_mix && ns_ub > 0 && nn_ub > 0 && !tail_next && (uint64_t)ns_ub + nn_ub <= mix_paths) {
                 // the shadow rays of this bounce and the rays of the next one in one launch
                 if ((rc = t_begin(5)) != RT_OK) return rc;
                 launch_mixed(rt_trace_grid((size_t)ns_ub + nn_ub), pn);
@@ -1648,8 +1261,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
                 return RT_ERR_HIP;
             }
             if (n_b == 0) continue;  // a bounce enqueued on a stale bound after the last path had died
-            if (!late[b]) iter += 1;  // records are shaded at their own bounce index: pa.tail[8] has the highest
-            if (hist[b].late) st.launches_tail += 1;  // k_late counts the rays it starts itself (pa.tail[0], [1])
+            iter += 1;
             st.rays_shadow += hist[b].n_skipped;  // issued by the reference's algorithm, traced by nobody
             st.rays_shadow_skipped += hist[b].n_skipped;
             if (hist[b].extend) {
@@ -1679,7 +1291,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     }
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev[1], stream));
-    unsigned long long visit[4] = {0, 0, 0, 0}, tail[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long visit[4] = {0, 0, 0, 0}, tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (count) RT_HIP(hipMemcpyAsync(visit, pa.visit, sizeof visit, hipMemcpyDeviceToHost, stream));
     if (st.launches_tail) RT_HIP(hipMemcpyAsync(tail, pa.tail, sizeof tail, hipMemcpyDeviceToHost, stream));  // tail and mixed launches
     if (host_out) RT_HIP(hipMemcpyAsync(rgb_sum, d_sum, sum_bytes, hipMemcpyDeviceToHost, stream));
@@ -1697,7 +1309,6 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     st.tris_tested = visit[1] + tail[3];
     st.nodes_visited_shadow = visit[2] + tail[4];
     st.tris_tested_shadow = visit[3] + tail[5];
-    if ((uint32_t)tail[8] > st.iterations) st.iterations = (uint32_t)tail[8];
     st.ms_tail = stage_ms[5];
     st.lean_kernels = lean ? 1u : 0u;
     st.nodes_visited_shadow_tail = tail[4];
@@ -1723,7 +1334,7 @@ extern "C" int rt_debug_occupancy(int* out4) {  // resident workgroups per CU: e
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_extend<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_shadow<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend_lean, RT_BLOCK, 0) != hipSuccess) return -2;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_shade<false, false>, SHADE_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_shade, SHADE_BLOCK, 0) != hipSuccess) return -2;
     return 0;
 }
 extern "C" int rt_debug_trace_stats(unsigned long long* out32, int reset) {

@@ -60,13 +60,6 @@ def _check(ctx, desc, w, h, spp, depth, seed=0, spp_first=0, max_paths=None):
         assert (st3.rays_closest, st3.rays_shadow) == (ost.rays_closest, ost.rays_shadow)
         assert st3.iterations == st.iterations
     assert st3.launches_extend >= st3.iterations
-    # the late-round machinery (paths as records, budgeted launches that set walks aside and resume them a round later,
-    # per-path bounce indices, the tail kernel taking records over) forced onto the whole frame: same image, same rays
-    for fl in (rt.api.RENDER_LATE_STRESS, rt.api.RENDER_LATE_STRESS2):
-        img5, st5 = ctx.render(w, h, spp, depth, seed, spp_first, flags=fl)
-        assert np.array_equal(img5.view(np.uint32), ref.view(np.uint32)), fl
-        assert (st5.rays_closest, st5.rays_shadow) == (ost.rays_closest, ost.rays_shadow), fl
-        assert st5.rays_shadow_skipped == st2.rays_shadow_skipped and st5.iterations == st.iterations, fl
     ctx.set_max_paths_in_flight(0)
     return img, st, ost
 
