@@ -18,9 +18,12 @@ workload "trace": BASELINE.json configs[1] -- primary + shadow rays only, same m
     shadow rays of the pixels that hit.
 
 Prints ONE JSON line (rank 0).  `value` = rays traced by all ranks / max-over-ranks wall time, rays
-= Engine::hit + Engine::hit_bool calls (SURVEY.md 8d).  `roofline` prices the dominant kernel
-(closest-hit traversal) with the algorithmic bytes 48 + 64*N_int + 40*N_tri per ray against 8 TB/s;
-its duration comes from HIP events on the library's own stream.  `cpu_baseline` times the oracle
+= Engine::hit + Engine::hit_bool calls (SURVEY.md 8d).  `roofline` is about the dominant kernel (closest-hit
+traversal, k_extend): `frac` = MEMORY-SIDE bytes per launch (rocprofv3 counters of this build, committed under
+profiles/) / the kernel's duration (HIP events on the library's own stream, measured in this run) / 8 TB/s.  The
+SURVEY.md 8(d) figure -- algorithmic bytes 48 + 64*N_int + 40*N_tri per ray / kernel time -- is printed beside it as
+`requested_GBs`: those are bytes the lanes REQUEST, most of them served by the vector L1 and the L2 (it exceeds the HBM
+peak), compared under `levels` with the measured rate of per-lane 64-byte gathers.  `cpu_baseline` times the oracle
 (oracle/, the C++ restatement of the reference: "port") on a bounded sample of the same workload on
 this box's host cores.  The oracle is used here only as that baseline/cross-check.
 """
@@ -36,10 +39,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Vector-L1 return path: 256 CUs x 64 B/clk x 2.4 GHz (a 64-lane dwordx4 load occupies the texture-data path for 16
-# cycles, profiles/r01/tuning.md section 12).  The ceiling of per-lane record gathers that hit on chip.
-L1_PEAK_GBS = 256 * 64 * 2.4
-L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: L2 aggregate
+# MEASURED ceiling of the traversal's access shape when every line hits the vector L1: 64 lanes each reading their own
+# 64-byte record with four global_load_dwordx4 (scripts/microbench/gather_lanes.hip, rows L64/1 of
+# profiles/r03/gather_lanes*.txt: 202-259 G records/s on tables <= 0.5 MiB, median 214 = 13.7 TB/s; 58 G records/s =
+# 3.7 TB/s from a 64 MiB table).  The requested-bytes figure is compared with this, not with a datasheet product.
+GATHER_L1_GBS = 214.0 * 64
 
 
 def parse():
@@ -298,24 +302,28 @@ def main():
         traffic, traffic_detail = committed_traffic(args, result["kernel"], rt.api.build_id(), world)
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays_per_step * args.steps / elapsed / 1e6
-        achieved = result["alg_bytes"] / (result["kernel_ms"] * 1e-3) / 1e9
-        # Which ceiling binds.  The algorithmic bytes are what the lanes REQUEST (64 B per node visit, 40 B per triangle
-        # test); the vector L1 and the L2 serve most of them, so the same launch loads two ceilings at
-        # once: the vector-L1 return path with the algorithmic bytes, and the memory side (Infinity Cache + HBM) with
-        # the bytes the counters see leave the L2.  The bound is the one with the larger fraction of its peak; the
-        # memory-side figure exists only when a counter profile of THIS build and workload is committed.
+        requested = result["alg_bytes"] / (result["kernel_ms"] * 1e-3) / 1e9
+        # Two figures for one launch.  MEMORY SIDE: the bytes the counters see leave the L2 towards Infinity Cache and HBM
+        # (FETCH_SIZE x the factor calibrated for the kernel's access shape + WRITE_SIZE, per launch, from the committed
+        # counter profile of THIS build and workload) / this run's kernel time, against the 8 TB/s HBM peak: the headline
+        # `frac`.  REQUESTED: SURVEY.md 8(d)'s algorithmic bytes / kernel time -- what the lanes ask for; the vector L1 and
+        # the L2 serve most of it, so it exceeds the HBM peak and is no fraction of it; it is compared with the measured
+        # rate of the same access shape on L1-resident data (levels.l1_gather_path).
         geom_bytes = scene.flat.n_tris * 48 + max(0, scene.flat.n_nodes - scene.flat.n_bvhs) * 32
-        frac_l1 = achieved / L1_PEAK_GBS
-        levels = {"l1_return_path": {"achieved_GBs": round(achieved, 1), "peak_GBs": round(L1_PEAK_GBS, 1),
-                                     "frac": round(frac_l1, 4), "bytes": "algorithmic (requested by the lanes)"}}
-        hbm_bound, t_gbs = False, None
+        levels = {"l1_gather_path": {"achieved_GBs": round(requested, 1), "peak_GBs": round(GATHER_L1_GBS, 1),
+                                     "frac": round(requested / GATHER_L1_GBS, 4),
+                                     "bytes": "requested by the lanes (algorithmic)",
+                                     "peak_source": "measured: 64 lanes x own 64-B record, L1-resident table (profiles/r03/gather_lanes*.txt, L64/1)"}}
         if traffic is not None:
             t_gbs = traffic / (result["kernel_ms"] * 1e-3) / 1e9
             levels["memory_side"] = {"achieved_GBs": round(t_gbs, 1), "peak_GBs": HBM_PEAK_GBS, "frac": round(t_gbs / HBM_PEAK_GBS, 4),
                                      "frac_of_stream_copy": round(t_gbs / stream_copy, 4),
-                                     "bytes": "FETCH_SIZE x2 + WRITE_SIZE (fabric side of L2: Infinity Cache + HBM)"}
-            hbm_bound = t_gbs / HBM_PEAK_GBS > frac_l1
-        roof_achieved, peak = (t_gbs, HBM_PEAK_GBS) if hbm_bound else (achieved, L1_PEAK_GBS)
+                                     "bytes": "FETCH_SIZE x calibrated factor + WRITE_SIZE (fabric side of L2: Infinity Cache + HBM)"}
+            roof_achieved, roof_note = t_gbs, ("achieved = memory-side counter bytes per launch (traffic) / kernel time of this run; peak = HBM 8 TB/s. "
+                                               "requested_GBs is SURVEY 8(d)'s algorithmic figure: requested bytes, cache-served")
+        else:  # no counter profile of this build: only SURVEY 8(d)'s literal figure can be given (requested bytes, cache-served)
+            roof_achieved, roof_note = requested, ("NO counter profile of this build is committed: achieved = SURVEY 8(d)'s algorithmic bytes / kernel "
+                                                   "time, i.e. REQUESTED bytes, mostly served by L1/L2 -- not HBM traffic, frac is not a utilisation")
         out = {
             "metric": "Mrays/s (path-segment rays, whole node)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -325,15 +333,13 @@ def main():
                        "parallelism": (f"sample-sharded x{world} ({args.scaling}), {result.get('reduce', 'none')}" if world > 1 else "1 GPU"),
                        "ms_per_frame": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1),
                        "geometry_bytes": int(geom_bytes), "build": rt.api.build_id()},
-            "roofline": {"bound": "hbm" if hbm_bound else "l1", "achieved": round(roof_achieved, 1), "peak": round(peak, 1), "unit": "GB/s",
-                         "frac": round(roof_achieved / peak, 4), "traffic": traffic, "algorithmic_GBs": round(achieved, 1),
-                         "bound_note": ("the memory side is the more loaded ceiling: achieved = counter bytes (traffic) / kernel time against "
-                                        "HBM 8 TB/s; the algorithmic bytes are in levels.l1_return_path" if hbm_bound else
-                                        "the vector-L1 return path (256 CUs x 64 B/clk x 2.4 GHz) is the more loaded ceiling: achieved = algorithmic "
-                                        "bytes / kernel time; the tree is served on chip, levels.memory_side (when a counter profile of "
-                                        "this build is committed) gives the HBM-side fraction"),
+            "roofline": {"bound": "hbm", "achieved": round(roof_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(roof_achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "requested_GBs": round(requested, 1), "requested_over_hbm_peak": round(requested / HBM_PEAK_GBS, 4),
+                         "note": roof_note,
                          "levels": levels,
-                         "traffic_unit": "bytes per launch (PMC, committed profile of this build)", "traffic_detail": traffic_detail,
+                         "traffic_unit": "memory-side bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, committed profile of this build)",
+                         "traffic_detail": traffic_detail,
                          "stream_copy_GBs": round(stream_copy, 1),
                          "kernel": result["kernel"], "kernel_ms": round(result["kernel_ms"], 4),
                          "alg_bytes_per_launch": int(result["alg_bytes"]),
@@ -389,6 +395,7 @@ def committed_traffic(args, kernel, build, world):
                 and w.get("instanced", False) == bool(getattr(args, "instanced", False)) and kernel in d.get("kernels", {})):
             k = d["kernels"][kernel]
             return k["hbm_bytes_per_launch"], {"fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
+                                               "fetch_factor": k.get("fetch_factor"),
                                                "launches": k["launches"], "l2_hit_rate": k.get("l2_hit_rate"),
                                                "source": os.path.relpath(f, ROOT), "build": d.get("build"), "note": d.get("note", "")}
     return None, None

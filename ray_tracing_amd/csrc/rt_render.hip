@@ -92,9 +92,12 @@ struct RenderParams {
     uint32_t k0, k1;        // Philox key = seed
     uint32_t bounce;        // k_shade: RNG bounce index of this wavefront iteration (= iteration + 1)
     uint32_t skip_zero_nee;   // do not trace shadow rays whose light term is exactly zero (not when counting the reference's visits)
-    uint32_t implicit_first;  // the first bounce's origin, throughput, depth and medium are the same for every
-                              // path (camera origin, 1, rp.depth, initial medium): k_generate does not store
-                              // them and the first extend / shade do not load them (64 B per path less traffic)
+    uint32_t implicit_first;  // the first bounce's state is a function of the slot alone: origin, throughput, depth and
+                              // medium are the same for every path (camera origin, 1, rp.depth, initial medium), the
+                              // direction is Camera::ray of the slot's jitter draws (camera_ray_dir), the radiance is 0.
+                              // k_generate then stores nothing: the first extend and shade recompute the direction
+                              // (one Philox block and a normalisation against 16 B written and 32 B read per path) and
+                              // the first shade writes every path's radiance record instead of reading it
 };
 // Which (pixel, sample in batch) a path's original slot names.  Pixel-major: the 64 lanes of a wave start with up to
 // 64 samples of ONE pixel -- rays a fraction of a pixel apart, which walk the same nodes down to the leaves (one
@@ -119,7 +122,20 @@ RT_DEV float pack_medium(int medium, bool prev_specular) {
 }
 
 // ---------------------------------------------------------------- generate
-// Position = slot: every segment but the last starts full.  Block 0 also writes the counts of bounce 0.
+// Camera::ray (camera.rs:60-63) of the jittered (u, v) of path_integrator.rs:303-305 for (pixel, sample in batch): the two
+// draws of RNG bounce 0.  One definition for k_generate and for the kernels that recompute it (RenderParams::implicit_first).
+RT_DEV V3 camera_ray_dir(const DScene& sc, const RenderParams& rp, uint32_t pixel, uint32_t s_local) {
+    const uint32_t i = pixel % rp.width, j = pixel / rp.width;
+    Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + s_local, 0u, 0u};
+    const float u = ((float)i + rng.f32()) / (float)(rp.width - 1);
+    const float v = ((float)j + rng.f32()) / (float)(rp.height - 1);
+    const V3 origin = ld3(sc.camera.origin);
+    const V3 dir = ld3(sc.camera.lower_left_corner) + u * ld3(sc.camera.horizontal) + v * ld3(sc.camera.vertical) - origin;
+    return normalise(dir);
+}
+
+// Position = slot: every segment but the last starts full.  Block 0 also writes the counts of bounce 0; with
+// RenderParams::implicit_first that is all there is to do (one block is launched).
 __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, RenderParams rp, uint32_t n_paths, rt_rays ur,
                                                   uint32_t* cnt0) {
     uint32_t slot = blockIdx.x * 256u + threadIdx.x;
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
             cnt0[CNT_TOT_SHADOW] = 0u;
         }
     }
-    if (slot >= n_paths) return;
+    if (slot >= n_paths || rp.implicit_first) return;
     uint32_t pixel, s_local;
     slot_pixel(rp, slot, &pixel, &s_local);
     V3 origin, dir;
@@ -140,20 +156,12 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
         origin = v3(ur.ox[pixel], ur.oy[pixel], ur.oz[pixel]);
         dir = v3(ur.dx[pixel], ur.dy[pixel], ur.dz[pixel]);
     } else {
-        uint32_t i = pixel % rp.width, j = pixel / rp.width;
-        Rng rng{rp.k0, rp.k1, pixel, rp.sample_first + s_local, 0u, 0u};
-        // path_integrator.rs:303-305
-        float u = ((float)i + rng.f32()) / (float)(rp.width - 1);
-        float v = ((float)j + rng.f32()) / (float)(rp.height - 1);
         origin = ld3(sc.camera.origin);
-        dir = ld3(sc.camera.lower_left_corner) + u * ld3(sc.camera.horizontal) + v * ld3(sc.camera.vertical) - origin;
-        dir = normalise(dir);  // camera.rs:60-63
+        dir = camera_ray_dir(sc, rp, pixel, s_local);
     }
     // :139-148: beta = 1, radiance = 0, prev_pdf = 1, prev_specular = true, current medium = initial
-    if (!rp.implicit_first) {
-        pa.ray_o[slot] = make_float4(origin.x, origin.y, origin.z, pack_medium(sc.initial_medium, true));
-        pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rp.depth));
-    }
+    pa.ray_o[slot] = make_float4(origin.x, origin.y, origin.z, pack_medium(sc.initial_medium, true));
+    pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rp.depth));
     pa.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
     pa.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
@@ -170,21 +178,26 @@ RT_DEV void add_visits(unsigned long long* dst, unsigned long long a, unsigned l
     }
 }
 
-struct ExtendIO {  // ray i = the path at position i; hits go to the position's hit record
+// FIRST: 1 = always the first bounce of an implicit frame, 0 = never, -1 = decided at run time (`first`).  The lean kernel has
+// one instantiation for each: with both ray sources in one kernel the loop loses registers to scalar spills.
+template <int FIRST = -1>
+struct ExtendIOT {  // ray i = the path at position i; hits go to the position's hit record
     PathArrays pa;
     unsigned long long n_int, n_tri;
-    bool first;       // first bounce with implicit state (RenderParams::implicit_first): every ray starts at the camera
-    float cam[3];     // ... whose origin travels by value (a pointer into the kernel arguments turns the load of the
-                      // origin into a flat load of a selected address)
+    bool first;       // first bounce with implicit state (RenderParams::implicit_first): Camera::ray of the slot, nothing is loaded
+    const DScene& sc;
+    const RenderParams& rp;
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // returns the position: the ray's tag from here on
-        float4 d4 = pa.ray_d[i];
-        if (first) {  // uniform
-            *o = v3(cam[0], cam[1], cam[2]);
+        if (FIRST > 0 || (FIRST < 0 && first)) {  // uniform
+            uint32_t pixel, s_local;
+            slot_pixel(rp, i, &pixel, &s_local);
+            *o = ld3(sc.camera.origin);
+            *d = camera_ray_dir(sc, rp, pixel, s_local);
         } else {
-            float4 o4 = pa.ray_o[i];
+            float4 o4 = pa.ray_o[i], d4 = pa.ray_d[i];
             *o = v3(o4.x, o4.y, o4.z);
+            *d = v3(d4.x, d4.y, d4.z);
         }
-        *d = v3(d4.x, d4.y, d4.z);
         return i;
     }
     // a closer hit than any before it on this ray (Engine::hit's `closest = Some(..)`, :92-94)
@@ -205,6 +218,7 @@ struct ExtendIO {  // ray i = the path at position i; hits go to the position's 
     }
     RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
 };
+typedef ExtendIOT<-1> ExtendIO;
 
 // launch-wide tuning of a render trace kernel: n_seg segments of seg_cap positions, counts in device memory
 RT_DEV TraceTune render_tune(const TuneBase& b, uint32_t n_total, uint32_t n_seg, uint32_t seg_cap) {
@@ -220,13 +234,13 @@ RT_DEV TraceTune render_tune(const TuneBase& b, uint32_t n_total, uint32_t n_seg
 }
 
 template <int COUNT>
-__global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, uint32_t first, TuneBase base, uint32_t* overflow,
+__global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, RenderParams rp, uint32_t first, TuneBase base, uint32_t* overflow,
                                        uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n = pa.cnt[CNT_TOT_ALIVE];
     const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
-    ExtendIO io{pa, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
+    ExtendIO io{pa, 0ull, 0ull, first != 0u, sc, rp};
     trace_loop<TRACE_CLOSEST, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
                                                              lds_stack + threadIdx.x, overflow + gtid, overflow_stride,
                                                              pa.cnt + CNT_ALIVE);
@@ -234,13 +248,14 @@ __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, uint32_t first,
 }
 
 // The same kernel for scenes whose objects are meshes and planes (rtd::SceneFeatures): fewer registers, more waves.
-__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, uint32_t first, TuneBase base, uint32_t* overflow,
+template <int FIRST>
+__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, RenderParams rp, TuneBase base, uint32_t* overflow,
                                                  uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n = pa.cnt[CNT_TOT_ALIVE];
     const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
-    ExtendIO io{pa, 0ull, 0ull, first != 0u, {sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2]}};
+    ExtendIOT<FIRST> io{pa, 0ull, 0ull, FIRST != 0, sc, rp};
     trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
         sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_ALIVE);
 }
@@ -330,18 +345,24 @@ struct ShadeOut {
     uint32_t id;        // the path's original slot
 };
 
-// One iteration of the loop body of ray_colour for the path at position `slot`.  Returns QF_* flags.
-RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot,
-                           uint32_t bounce, ShadeOut& out) {
+// One iteration of the loop body of ray_colour for the path at position `slot`.  Returns QF_* flags; *rad_written: the
+// path's radiance record was stored (it is only ever stored where something is added to it).
+RT_DEV uint32_t shade_path_body(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot,
+                                uint32_t bounce, ShadeOut& out, bool* rad_written) {
     // Everything the slot names is requested at once: nothing below depends on anything but `slot`, and a
     // wave that waits for each record in turn spends its time in memory round trips (4 waves per SIMD).
-    float4 d4 = pa.ray_d[slot], o4, b4;
+    float4 d4, o4, b4;
     const uint2 hb = pa.hit_b[slot];
     float4 ha = pa.hit_a[slot];
-    if (rp.implicit_first) {  // uniform: the state k_generate left implicit (:139-148)
+    if (rp.implicit_first) {  // uniform: the state k_generate left implicit (:139-148), position = slot
+        uint32_t px, sl;
+        slot_pixel(rp, slot, &px, &sl);
+        const V3 cd = camera_ray_dir(sc, rp, px, sl);
+        d4 = make_float4(cd.x, cd.y, cd.z, 1.0f);
         o4 = make_float4(sc.camera.origin[0], sc.camera.origin[1], sc.camera.origin[2], pack_medium(sc.initial_medium, true));
         b4 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rp.depth));
     } else {
+        d4 = pa.ray_d[slot];
         o4 = pa.ray_o[slot];
         b4 = pa.beta[slot];
     }
@@ -390,7 +411,8 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         }
         if (light >= 0) {
             V3 emitted = ld3(sc.lights[light].intensity);
-            float4 r = pa.rad[id];
+            float4 r = rp.implicit_first ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pa.rad[id];  // :140: radiance starts at 0
+            *rad_written = true;
             V3 add = mul_elemwise(beta, emitted);
             if (!prev_specular) {
                 float p_light = (1.0f / (float)sc.n_lights) * light_pdf(sc.lights[light], ro, rd);  // :162
@@ -414,7 +436,8 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
         if (k == MI_NULL) {
             beta = beta * transmittance;
         } else if (k == MI_ABSORPTION) {
-            float4 r = pa.rad[id];
+            float4 r = rp.implicit_first ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pa.rad[id];
+            *rad_written = true;
             V3 add = mul_elemwise(beta, mi.emission);
             r.x += add.x;
             r.y += add.y;
@@ -490,6 +513,15 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
     out.d4 = make_float4(nd.x, nd.y, nd.z, prev_pdf);
     out.b4 = make_float4(beta.x, beta.y, beta.z, __uint_as_float(depth));
     if (depth > 0) flags |= QF_ALIVE;
+    return flags;
+}
+
+RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot, uint32_t bounce,
+                           ShadeOut& out) {
+    bool rad_written = false;
+    const uint32_t flags = shade_path_body(sc, pa, rp, slot, bounce, out, &rad_written);
+    // first bounce of a frame whose k_generate stored nothing: every path's radiance record gets its first value here
+    if (rp.implicit_first && !rad_written) pa.rad[out.id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     return flags;
 }
 
@@ -1074,13 +1106,15 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     // kernel selection by counting mode / scene features, one place each
     auto launch_extend = [&](int grid, const PathArrays& q, uint32_t first) {
         if (count == rtd::COUNT_REFERENCE)
-            hipLaunchKernelGGL(k_extend<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, first, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_extend<rtd::COUNT_REFERENCE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, first, tune, overflow, ostride);
         else if (count == rtd::COUNT_FETCHES)
-            hipLaunchKernelGGL(k_extend<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, first, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_extend<rtd::COUNT_FETCHES>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, first, tune, overflow, ostride);
+        else if (lean && first)
+            hipLaunchKernelGGL(k_extend_lean<1>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, tune, overflow, ostride);
         else if (lean)
-            hipLaunchKernelGGL(k_extend_lean, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, first, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_extend_lean<0>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, tune, overflow, ostride);
         else
-            hipLaunchKernelGGL(k_extend<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, first, tune, overflow, ostride);
+            hipLaunchKernelGGL(k_extend<rtd::COUNT_NONE>, dim3(grid), dim3(RT_BLOCK), 0, stream, ctx->scene, q, rp, first, tune, overflow, ostride);
     };
     auto launch_shadow = [&](int grid, const PathArrays& q) {
         if (count == rtd::COUNT_REFERENCE)
@@ -1156,7 +1190,7 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         uint32_t seg_ub = std::min<uint64_t>(n_ub, (uint64_t)seg_cap * (NSEG / ns_of[0]));
         RT_HIP(hipMemsetAsync(base + o_acc, 0, zero_bytes, stream));  // accumulators, skipped total, work counters
         if ((rc = t_begin(0)) != RT_OK) return rc;
-        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, view(0), rp, n_paths, gen_rays, counts);
+        hipLaunchKernelGGL(k_generate, dim3(implicit ? 1u : (n_paths + 255) / 256), dim3(256), 0, stream, ctx->scene, view(0), rp, n_paths, gen_rays, counts);
         if ((rc = t_end(0)) != RT_OK) return rc;
         st.paths += n_paths;
         st.batches += 1;
@@ -1333,7 +1367,7 @@ extern "C" int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
 extern "C" int rt_debug_occupancy(int* out4) {  // resident workgroups per CU: extend, shadow, extend_lean, shade
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_extend<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_shadow<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend_lean, RT_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend_lean<0>, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_shade, SHADE_BLOCK, 0) != hipSuccess) return -2;
     return 0;
 }
