@@ -115,10 +115,15 @@ enum CountMode { COUNT_NONE = 0, COUNT_REFERENCE = 1, COUNT_FETCHES = 2 };
 template <int MODE, int COUNT, int STACK_LDS, int BLOCK, uint32_t FEAT = FEAT_ALL, bool OVERFLOW = true, class IO>
 RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_counter, const TraceTune tune, float t_min,
                        float t_max_in, uint32_t* lds, uint32_t* overflow, uint32_t overflow_stride,
-                       const uint32_t* seg_counts = nullptr, uint32_t counter_first = 0u) {
+                       const uint32_t* seg_counts = nullptr, uint32_t counter_first = 0u, const uint32_t* live_segs = nullptr) {
     // The launch's items: segment s holds items [s * seg_len, s * seg_len + count(s)).  count(s) comes from device
     // memory (rt_render: the survivors of a bounce are compacted per segment, rt_render.hip) or, without it, the n
     // items are contiguous and every segment but the last is full.
+    // live_segs (with seg_counts): [0] = number of segments that have items, [1..] = their indices.  A wave's home segment is
+    // one of THOSE (block index mod their number).  With block index mod n_seg, every wave whose home segment is empty --
+    // a frame whose geometry covers the middle bands of the image leaves the outer bands' segments without survivors --
+    // moves to the first segment with items after it: all of them to the same one, which they drain on one counter (~15 ns
+    // an atomic), then on together to the next.  Config 1's second bounce took 0.74 ms that way instead of 0.15.
     // work_counter: WORK_BUF_U32 zeroed u32 -- 2 * WORK_MAX_SEG counters, one 128-byte line each, then two 64-bit masks of
     // the counters whose last chunk has been handed out.  Segment s of this launch draws from counter counter_first + s
     // (rt_render runs a shadow launch on counters 64.. and the next closest-hit launch on counters 0.. between two
@@ -144,6 +149,10 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
         return first >= n ? 0u : (uint32_t)min((unsigned long long)tune.seg_len, (unsigned long long)n - first);
     };
     uint32_t seg = blockIdx.x % tune.n_seg;  // wave-uniform: the segment the wave draws from (first: its home segment)
+    if (live_segs) {
+        const uint32_t n_live = live_segs[0];
+        if (n_live != 0u && n_live <= tune.n_seg) seg = min(live_segs[1u + blockIdx.x % n_live], tune.n_seg - 1u);
+    }
     // wave-uniform: segments this wave need not ask (again): empty from the start, or found drained
     unsigned long long dead_lo = __builtin_amdgcn_ballot_w64(lane >= tune.n_seg || seg_count(lane) == 0u);
     unsigned long long dead_hi = tune.n_seg > 64u ? __builtin_amdgcn_ballot_w64(lane + 64u >= tune.n_seg || seg_count(lane + 64u) == 0u) : ~0ull;

@@ -52,8 +52,11 @@ constexpr uint32_t ACC_STRIDE = 16;  // u64 between accumulators: one 128-byte l
 // counts block (u32), two of them, ping-pong over the bounces: [0, NSEG) shadow rays per segment of the bounce BEFORE
 // this one, [NSEG, 2 NSEG) paths alive per segment at this bounce, the totals, and at CNT_MIXED the 2 ns segments of a
 // mixed launch in its order (shadow rays of the ns segments, then the paths of the ns segments)
+// ... and three lists of the segments that HAVE items (their number, then their indices): the home segments of the trace
+// launches' waves (device_trace.h, live_segs) for a launch over the paths, over the shadow rays, over both (mixed order)
 constexpr uint32_t CNT_SHADOW = 0, CNT_ALIVE = NSEG, CNT_TOT_ALIVE = 2 * NSEG, CNT_TOT_SHADOW = 2 * NSEG + 1, CNT_MIXED = 2 * NSEG + 4,
-                   CNT_U32 = 4 * NSEG + 4;
+                   CNT_LIVE_ALIVE = 4 * NSEG + 4, CNT_LIVE_SHADOW = CNT_LIVE_ALIVE + NSEG + 1, CNT_LIVE_MIXED = CNT_LIVE_SHADOW + NSEG + 1,
+                   CNT_U32 = CNT_LIVE_MIXED + 2 * NSEG + 1 + 1;
 
 struct PathArrays {      // the arrays one bounce works on (all indexed by POSITION unless noted)
     // 16-byte records; the w lanes carry the scalar path state, so a bounce moves 3 records per path
@@ -143,9 +146,13 @@ __global__ __launch_bounds__(256) void k_generate(DScene sc, PathArrays pa, Rend
         const unsigned long long first = (unsigned long long)threadIdx.x * pa.seg_stride;
         cnt0[CNT_ALIVE + threadIdx.x] = (threadIdx.x >= pa.ns || first >= n_paths) ? 0u : (uint32_t)min((unsigned long long)pa.seg_stride, n_paths - first);
         cnt0[CNT_SHADOW + threadIdx.x] = 0u;
+        cnt0[CNT_LIVE_ALIVE + 1u + threadIdx.x] = threadIdx.x;  // the segments with paths are the first ones
         if (threadIdx.x == 0) {
             cnt0[CNT_TOT_ALIVE] = n_paths;
             cnt0[CNT_TOT_SHADOW] = 0u;
+            const unsigned long long full = ((unsigned long long)n_paths + pa.seg_stride - 1u) / pa.seg_stride;
+            cnt0[CNT_LIVE_ALIVE] = (uint32_t)min(full, (unsigned long long)pa.ns);
+            cnt0[CNT_LIVE_SHADOW] = cnt0[CNT_LIVE_MIXED] = 0u;
         }
     }
     if (slot >= n_paths || rp.implicit_first) return;
@@ -243,7 +250,7 @@ __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, RenderParams rp
     ExtendIO io{pa, 0ull, 0ull, first != 0u, sc, rp};
     trace_loop<TRACE_CLOSEST, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
                                                              lds_stack + threadIdx.x, overflow + gtid, overflow_stride,
-                                                             pa.cnt + CNT_ALIVE);
+                                                             pa.cnt + CNT_ALIVE, 0u, pa.cnt + CNT_LIVE_ALIVE);
     if (COUNT) add_visits(&pa.visit[0], io.n_int, io.n_tri);
 }
 
@@ -257,7 +264,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, Rende
     const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
     ExtendIOT<FIRST> io{pa, 0ull, 0ull, FIRST != 0, sc, rp};
     trace_loop<TRACE_CLOSEST, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
-        sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_ALIVE);
+        sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_ALIVE, 0u, pa.cnt + CNT_LIVE_ALIVE);
 }
 
 // ---------------------------------------------------------------- shadow-connect
@@ -303,7 +310,7 @@ __global__ RT_TRACE_ATTR_ANY void k_shadow(DScene sc, PathArrays pa, TuneBase ba
     const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
     ShadowIO io{pa, 0ull, 0ull};
     trace_loop<TRACE_ANY, COUNT, RT_STACK_ANY, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
-                                                         lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_SHADOW, NSEG);
+                                                         lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_SHADOW, NSEG, pa.cnt + CNT_LIVE_SHADOW);
     if (COUNT) add_visits(&pa.visit[2], io.n_int, io.n_tri);
 }
 
@@ -314,7 +321,7 @@ __global__ RT_TRACE_ATTR_LEAN_ANY void k_shadow_lean(DScene sc, PathArrays pa, T
     const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
     ShadowIO io{pa, 0ull, 0ull};
     trace_loop<TRACE_ANY, false, RT_STACK_LEAN_ANY, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
-        sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_SHADOW, NSEG);
+        sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_SHADOW, NSEG, pa.cnt + CNT_LIVE_SHADOW);
 }
 
 // ---------------------------------------------------------------- shade
@@ -595,6 +602,25 @@ __global__ __launch_bounds__(64) void k_publish(PathArrays pa, uint32_t* cnt_out
         cnt_out[CNT_MIXED + s] = sh;
         cnt_out[CNT_MIXED + pa.ns_out + s] = a;
     }
+    {  // the segments with items, in order: of the paths, of the shadow rays, of both in a mixed launch's order
+        const unsigned long long ma = __ballot(a != 0u), ms = __ballot(sh != 0u);
+        const uint32_t ra = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+        const uint32_t rs = __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
+        const uint32_t na = (uint32_t)__popcll(ma), nsh = (uint32_t)__popcll(ms);
+        if (a != 0u) {
+            cnt_out[CNT_LIVE_ALIVE + 1u + ra] = s;
+            cnt_out[CNT_LIVE_MIXED + 1u + nsh + ra] = pa.ns_out + s;
+        }
+        if (sh != 0u) {
+            cnt_out[CNT_LIVE_SHADOW + 1u + rs] = s;
+            cnt_out[CNT_LIVE_MIXED + 1u + rs] = s;
+        }
+        if (s == 0) {
+            cnt_out[CNT_LIVE_ALIVE] = na;
+            cnt_out[CNT_LIVE_SHADOW] = nsh;
+            cnt_out[CNT_LIVE_MIXED] = na + nsh;
+        }
+    }
     uint32_t ta = a, ts = sh, ma = a;
     for (int off = 32; off > 0; off >>= 1) {
         ta += __shfl_down(ta, off);
@@ -715,7 +741,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, PathArrays pa, Ren
     const TraceTune tune = render_tune(base, n, pa.ns, pa.seg_stride);
     TailIO io{pa, &sc, &rp, 0u, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, false, 0u};
     trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
-                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_ALIVE);
+                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_ALIVE, 0u, pa.cnt + CNT_LIVE_ALIVE);
     unsigned long long v[6] = {io.n_closest, io.n_shadow, io.n_int, io.n_tri, io.n_int_sh, io.n_tri_sh};
     uint32_t mx = io.max_iters;
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
@@ -794,7 +820,7 @@ __global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, TuneBase base, u
     const TraceTune tune = render_tune(base, n, 2u * pa.ns, pa.seg_stride);
     MixedIO io{pa, pa.n_positions, 0ull, 0ull, 0ull, 0ull};
     trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
-                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_MIXED);
+                                                          lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_MIXED, 0u, pa.cnt + CNT_LIVE_MIXED);
     if (COUNT) {  // accounted with the tail kernel's share: rays traced outside k_extend / k_shadow
         add_visits(&pa.tail[2], io.n_int, io.n_tri);
         add_visits(&pa.tail[4], io.n_int_sh, io.n_tri_sh);
@@ -808,7 +834,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays pa, TuneBa
     const TraceTune tune = render_tune(base, n, 2u * pa.ns, pa.seg_stride);
     MixedIO io{pa, pa.n_positions, 0ull, 0ull, 0ull, 0ull};
     trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
-        sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_MIXED);
+        sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_MIXED, 0u, pa.cnt + CNT_LIVE_MIXED);
 }
 
 // ---------------------------------------------------------------- resolve

@@ -15,10 +15,10 @@ agg = collections.defaultdict(float)
 calls = collections.defaultdict(set)
 for f in glob.glob(os.path.join(d, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_[a-z_]+(<[0-9]>)?)", r["Kernel_Name"])
+        m = re.search(r"(k_[a-z_]+)(<[0-9]>)?", r["Kernel_Name"])
         if not m:
             continue
-        k = m.group(1)
+        k = m.group(1)  # instantiations of one kernel (k_extend_lean<1>: first bounce, <0>: later ones) are one entry
         agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
         calls[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 kernels = {}
