@@ -100,7 +100,7 @@ struct RenderParams {
                               // direction is Camera::ray of the slot's jitter draws (camera_ray_dir), the radiance is 0.
                               // k_generate then stores nothing: the first extend and shade recompute the direction
                               // (one Philox block and a normalisation against 16 B written and 32 B read per path) and
-                              // the first shade writes every path's radiance record instead of reading it
+                              // the first extend stores the radiance records' zeros
 };
 // Which (pixel, sample in batch) a path's original slot names.  Pixel-major: the 64 lanes of a wave start with up to
 // 64 samples of ONE pixel -- rays a fraction of a pixel apart, which walk the same nodes down to the leaves (one
@@ -200,6 +200,9 @@ struct ExtendIOT {  // ray i = the path at position i; hits go to the position's
             slot_pixel(rp, i, &pixel, &s_local);
             *o = ld3(sc.camera.origin);
             *d = camera_ray_dir(sc, rp, pixel, s_local);
+            // :140: the path's radiance starts at 0.  Stored from here: this launch waits for node fetches, not for its
+            // stores (1 TB/s on the memory side), whereas the first shade is bound by the bytes it moves (+0.6 ms there)
+            pa.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         } else {
             float4 o4 = pa.ray_o[i], d4 = pa.ray_d[i];
             *o = v3(o4.x, o4.y, o4.z);
@@ -255,8 +258,11 @@ __global__ RT_TRACE_ATTR void k_extend(DScene sc, PathArrays pa, RenderParams rp
 }
 
 // The same kernel for scenes whose objects are meshes and planes (rtd::SceneFeatures): fewer registers, more waves.
+#ifndef RT_WAVES_EU_LEAN_FIRST
+#define RT_WAVES_EU_LEAN_FIRST RT_WAVES_EU_LEAN
+#endif
 template <int FIRST>
-__global__ RT_TRACE_ATTR_LEAN void k_extend_lean(DScene sc, PathArrays pa, RenderParams rp, TuneBase base, uint32_t* overflow,
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(FIRST > 0 ? RT_WAVES_EU_LEAN_FIRST : RT_WAVES_EU_LEAN))) void k_extend_lean(DScene sc, PathArrays pa, RenderParams rp, TuneBase base, uint32_t* overflow,
                                                  uint32_t overflow_stride) {
     __shared__ uint32_t lds_stack[RT_STACK_LEAN * RT_BLOCK];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -352,10 +358,9 @@ struct ShadeOut {
     uint32_t id;        // the path's original slot
 };
 
-// One iteration of the loop body of ray_colour for the path at position `slot`.  Returns QF_* flags; *rad_written: the
-// path's radiance record was stored (it is only ever stored where something is added to it).
-RT_DEV uint32_t shade_path_body(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot,
-                                uint32_t bounce, ShadeOut& out, bool* rad_written) {
+// One iteration of the loop body of ray_colour for the path at position `slot`.  Returns QF_* flags.
+RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot,
+                           uint32_t bounce, ShadeOut& out) {
     // Everything the slot names is requested at once: nothing below depends on anything but `slot`, and a
     // wave that waits for each record in turn spends its time in memory round trips (4 waves per SIMD).
     float4 d4, o4, b4;
@@ -418,8 +423,7 @@ RT_DEV uint32_t shade_path_body(const DScene& sc, const PathArrays& pa, const Re
         }
         if (light >= 0) {
             V3 emitted = ld3(sc.lights[light].intensity);
-            float4 r = rp.implicit_first ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pa.rad[id];  // :140: radiance starts at 0
-            *rad_written = true;
+            float4 r = pa.rad[id];
             V3 add = mul_elemwise(beta, emitted);
             if (!prev_specular) {
                 float p_light = (1.0f / (float)sc.n_lights) * light_pdf(sc.lights[light], ro, rd);  // :162
@@ -443,8 +447,7 @@ RT_DEV uint32_t shade_path_body(const DScene& sc, const PathArrays& pa, const Re
         if (k == MI_NULL) {
             beta = beta * transmittance;
         } else if (k == MI_ABSORPTION) {
-            float4 r = rp.implicit_first ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pa.rad[id];
-            *rad_written = true;
+            float4 r = pa.rad[id];
             V3 add = mul_elemwise(beta, mi.emission);
             r.x += add.x;
             r.y += add.y;
@@ -520,15 +523,6 @@ RT_DEV uint32_t shade_path_body(const DScene& sc, const PathArrays& pa, const Re
     out.d4 = make_float4(nd.x, nd.y, nd.z, prev_pdf);
     out.b4 = make_float4(beta.x, beta.y, beta.z, __uint_as_float(depth));
     if (depth > 0) flags |= QF_ALIVE;
-    return flags;
-}
-
-RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderParams& rp, uint32_t slot, uint32_t bounce,
-                           ShadeOut& out) {
-    bool rad_written = false;
-    const uint32_t flags = shade_path_body(sc, pa, rp, slot, bounce, out, &rad_written);
-    // first bounce of a frame whose k_generate stored nothing: every path's radiance record gets its first value here
-    if (rp.implicit_first && !rad_written) pa.rad[out.id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     return flags;
 }
 
