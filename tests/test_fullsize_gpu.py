@@ -98,6 +98,32 @@ def test_config4_medium_full_resolution_subset(ctx):
     assert np.array_equal(img.reshape(-1, 3)[px].view(np.uint32), ref.view(np.uint32))
 
 
+def test_config1_full_frame_size_partly_covered_frame(ctx):
+    """configs[0] at its own frame size (400x225; 32 of its 256 spp: 2.9 M paths, eight segments): analytic spheres and the
+    checkered medium through the FULL (not lean) wavefront kernels, on a frame whose geometry covers the middle of the
+    image only -- after the first bounce the outer bands' segments are empty and the trace waves' home segments are dealt
+    among the ones that have paths (device_trace.h, live_segs).  Pixels over the sphere, beside it and random ones against
+    the oracle, bit for bit; ray counts of the whole frame against the reference-counting kernels."""
+    desc = scenes.volumetric_sphere()
+    scene = rt.Scene(desc)
+    ctx.upload(scene)
+    orc = ob.OracleScene(desc)
+    w, h, spp = 400, 225, 32
+    img, st = ctx.render(w, h, spp, 16, 31)
+    assert st.launches_extend >= 1 and st.launches_tail >= 2 and st.lean_kernels == 0 and st.paths == w * h * spp
+    org, dr = scenes.pixel_center_rays(scene.flat.camera, w, h)
+    objs = ctx.trace_closest(org, dr)["obj"]
+    ball, sky = np.flatnonzero(objs == 0), np.flatnonzero(objs != 0)
+    assert len(ball) > 5000 and len(sky) > 5000  # the sphere covers part of the frame
+    px = np.concatenate([np.random.default_rng(1).choice(ball, 500, replace=False),
+                         np.random.default_rng(2).choice(sky, 200, replace=False)]).astype(np.uint32)
+    ref, _ = orc.render_pixels(w, h, px, spp, 16, 31, threads=8)
+    assert np.array_equal(img.reshape(-1, 3)[px].view(np.uint32), ref.view(np.uint32))
+    img2, st2 = ctx.render(w, h, spp, 16, 31, flags=rt.api.RENDER_COUNT_VISITS)
+    assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
+    assert (st2.rays_closest, st2.rays_shadow) == (st.rays_closest, st.rays_shadow)
+
+
 def test_config5_instances_full_resolution_subset(ctx):
     """configs[4] pattern at full resolution: a plane and 10 translated instances of one mesh (65 536
     triangles each here, so that the oracle builds its trees in seconds).  The top level over objects
