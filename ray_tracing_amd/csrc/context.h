@@ -82,11 +82,11 @@ struct rt_ctx {
     uint32_t overflow_levels = 0;
     DevBuf staging[16];   // rt_trace_* host<->device staging
     // rt_render state
-    DevBuf path_state, queues, counters, sample_sum;
+    DevBuf path_state, counters, sample_sum;
     uint64_t max_paths_in_flight = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     float last_kernel_ms = 0.0f;
-    // rt_render: counts of every bounce arrive in pinned host memory (k_compact_scan_top writes them), one ring slot of
+    // rt_render: counts of every bounce arrive in pinned host memory (k_publish writes them), one ring slot of
     // 4 u32 and one event per bounce in flight; event pairs of the stage timers, reused from call to call
     uint32_t* rb_host = nullptr;
     hipEvent_t rb_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -278,7 +278,7 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->pairs, &ctx->objects, &ctx->materials, &ctx->lights, &ctx->media, &ctx->wbox,
-                      &ctx->overflow, &ctx->path_state, &ctx->queues, &ctx->counters, &ctx->sample_sum};
+                      &ctx->overflow, &ctx->path_state, &ctx->counters, &ctx->sample_sum};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->staging) b.release();
     if (ctx->rb_host) (void)hipHostFree(ctx->rb_host);

@@ -1,7 +1,9 @@
 // rt_render: Engine::render / Engine::ray_colour (path_integrator.rs:138-318) as a wavefront
 // pipeline on gfx950:
 //
-//   generate        one lane per (pixel, sample): jittered Camera::ray, initial path state
+//   generate        the counts of bounce 0; the first bounce's state is a function of the slot (camera origin, jittered
+//                   Camera::ray, throughput 1), recomputed where it is needed -- stored, one lane per (pixel, sample), only
+//                   for rt_ray_colour's caller rays and for frames the tail kernel takes from the start
 //   extend          one lane per live path: Engine::hit (closest hit through the BVH)
 //   shade           one lane per live path: one iteration of the `while depth > 0` loop --
 //                   light hit + MIS, medium majorant step, BSDF sample, NEE set-up, throughput,
