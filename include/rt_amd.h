@@ -347,6 +347,40 @@ void rt_comm_destroy(rt_comm* comm);
    that filled rgb_sum; returns when the result is complete.  24.9 MB at 1080p, 99.5 MB at 4K. */
 int rt_reduce_accum(rt_comm* comm, float* rgb_sum, uint32_t width, uint32_t height, int root);
 
+/* ---- frames in flight (no counterpart in the reference: Engine::render is one synchronous loop,
+   path_integrator.rs:278-318).  The late bounces of a frame are a few long walks that leave most of the GPU idle; a
+   pipeline renders up to `frames_in_flight` DIFFERENT frames at once on one GPU -- one context (stream, scene copy,
+   path state) and one host thread each, frames dealt round-robin, every frame by the unchanged rt_render (same bits
+   as a lone call) -- so that the large launches of one frame fill what the late launches of another leave empty.
+   Throughput, not latency: a frame in a full pipeline takes longer than alone.  One host thread drives a pipeline. */
+typedef struct rt_pipeline rt_pipeline;
+#define RT_PIPELINE_MAX_FRAMES 8
+#define RT_PIPELINE_NO_REDUCE (-2) /* reduce_root: render only */
+int rt_pipeline_create(int device, uint32_t frames_in_flight, rt_pipeline** out);
+/* Renders what is still queued, then releases the communicators and the contexts. */
+void rt_pipeline_destroy(rt_pipeline* pipe);
+uint32_t rt_pipeline_frames(const rt_pipeline* pipe);
+/* The context of one slot, borrowed: for settings (rt_set_visit_count_mode, ...) and for plain rt_render calls
+   while no frame is in flight. */
+rt_ctx* rt_pipeline_context(rt_pipeline* pipe, uint32_t slot);
+/* rt_upload_scene on every context (one scene copy each); shares 80 % of the free HBM among the contexts' path
+   states (rt_set_max_paths_in_flight).  Only while no frame is in flight (RT_ERR_STATE otherwise). */
+int rt_pipeline_upload_scene(rt_pipeline* pipe, const rt_scene_flat* scene);
+/* Multi-GPU: one communicator per slot from ids[frames_in_flight][RT_COMM_ID_BYTES] (rt_comm_unique_id on one rank,
+   once per slot), created slot by slot -- collective, every rank calls it with the same ids. */
+int rt_pipeline_comm_create(rt_pipeline* pipe, const uint8_t* ids, int world_size, int rank);
+/* Queues one rt_render call (same arguments; rgb_sum must stay valid and untouched until the frame has been waited
+   for, and frames in flight need distinct buffers) and returns its ticket at once.  reduce_root >= 0 / -1: the frame
+   is followed by rt_reduce_accum onto that rank / onto every rank (rgb_sum must be device memory); the reduces of
+   successive frames are issued in submission order, one at a time, whatever order the frames finish in -- every
+   rank must submit the same frames in the same order.  RT_PIPELINE_NO_REDUCE: none. */
+int rt_pipeline_submit(rt_pipeline* pipe, uint32_t width, uint32_t height, uint32_t spp_first, uint32_t spp_count,
+                       uint32_t depth, uint64_t seed, uint32_t flags, float* rgb_sum, int reduce_root, uint64_t* ticket);
+/* Blocks until the frame (and its reduce) is complete; returns ITS status, with the text in rt_last_error() on the
+   calling thread, and its statistics (the ms_* fields are stream times that include the other frames' kernels).
+   Every ticket is waited for exactly once. */
+int rt_pipeline_wait(rt_pipeline* pipe, uint64_t ticket, rt_stats* stats);
+
 /* Engine::ray_colour (path_integrator.rs:138-276, the crate's public per-ray entry) in batch form: rgb_sum[3k..] =
    sum over the samples [spp_first, spp_first + spp_count) of ray_colour(ray k, depth).  Ray k is taken as it is (the
    reference's callers pass Camera::ray's normalised direction); the random numbers of (ray k, sample s) are those

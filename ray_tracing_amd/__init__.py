@@ -4,4 +4,4 @@
 benchmark scene descriptions.  Importing fails loudly if the HIP library has not been built.
 """
 from . import api, scenes  # noqa: F401
-from .api import Comm, Context, Mesh, RtError, Scene, SceneDescription, comm_unique_id  # noqa: F401
+from .api import Comm, Context, FramePipeline, Mesh, RtError, Scene, SceneDescription, comm_unique_id  # noqa: F401

@@ -126,6 +126,8 @@ EXPORTS = ["rt_mesh_create", "rt_mesh_read_stl", "rt_mesh_loop_subdivide", "rt_m
            "rt_scene_view", "rt_scene_destroy", "rt_tonemap_u8", "rt_write_ppm", "rt_create", "rt_destroy",
            "rt_upload_scene", "rt_initial_medium", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render", "rt_ray_colour",
            "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy", "rt_reduce_accum",
+           "rt_pipeline_create", "rt_pipeline_destroy", "rt_pipeline_frames", "rt_pipeline_context",
+           "rt_pipeline_upload_scene", "rt_pipeline_comm_create", "rt_pipeline_submit", "rt_pipeline_wait",
            "rt_set_max_paths_in_flight", "rt_set_visit_count_mode", "rt_last_kernel_ms", "rt_stream", "rt_last_error", "rt_version"]
 
 if not os.path.exists(LIB_PATH):
@@ -177,6 +179,18 @@ lib.rt_comm_destroy.argtypes = [C.c_void_p]
 lib.rt_comm_destroy.restype = None
 lib.rt_reduce_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
 lib.rt_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneFlat)]
+lib.rt_pipeline_create.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+lib.rt_pipeline_destroy.argtypes = [C.c_void_p]
+lib.rt_pipeline_destroy.restype = None
+lib.rt_pipeline_frames.argtypes = [C.c_void_p]
+lib.rt_pipeline_frames.restype = C.c_uint32
+lib.rt_pipeline_context.argtypes = [C.c_void_p, C.c_uint32]
+lib.rt_pipeline_context.restype = C.c_void_p
+lib.rt_pipeline_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneFlat)]
+lib.rt_pipeline_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+lib.rt_pipeline_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                   C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+lib.rt_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Stats)]
 lib.rt_set_max_paths_in_flight.argtypes = [C.c_void_p, C.c_uint64]
 lib.rt_set_visit_count_mode.argtypes = [C.c_void_p, C.c_uint32]
 
@@ -392,7 +406,11 @@ class Scene:
 class Context:
     """One GPU context (Engine): rt_create + rt_upload_scene."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
+        self._owner = None
+        if _borrowed is not None:  # a FramePipeline's context: the pipeline destroys it
+            self.handle, self._owner = C.c_void_p(_borrowed[0]), _borrowed[1]
+            return
         h = C.c_void_p()
         _check(lib.rt_create(C.c_int(device), C.byref(h)))
         self.handle = h
@@ -488,7 +506,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None) and lib is not None:
-            lib.rt_destroy(self.handle)
+            if getattr(self, "_owner", None) is None:
+                lib.rt_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -496,6 +515,7 @@ class Context:
 
 
 COMM_ID_BYTES = 128
+PIPELINE_NO_REDUCE = -2
 
 
 def comm_unique_id():
@@ -523,6 +543,53 @@ class Comm:
     def close(self):
         if getattr(self, "handle", None) and lib is not None:
             lib.rt_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+class FramePipeline:
+    """rt_pipeline: up to `frames_in_flight` frames rendered at once on one GPU, each by the unchanged rt_render."""
+
+    def __init__(self, device=0, frames_in_flight=2):
+        h = C.c_void_p()
+        _check(lib.rt_pipeline_create(C.c_int(device), frames_in_flight, C.byref(h)))
+        self.handle = h
+        self.frames_in_flight = lib.rt_pipeline_frames(h)
+
+    def upload(self, scene):
+        flat = scene.flat if isinstance(scene, Scene) else scene
+        _check(lib.rt_pipeline_upload_scene(self.handle, C.byref(flat)))
+
+    def context(self, slot=0):
+        """The slot's context, borrowed (settings; plain renders while no frame is in flight)."""
+        h = lib.rt_pipeline_context(self.handle, slot)
+        if not h:
+            raise RtError(-1, lib.rt_last_error().decode())
+        return Context(_borrowed=(h, self))
+
+    def comm_create(self, unique_ids, world_size, rank):
+        """unique_ids: one comm_unique_id() per slot, the same on every rank.  Collective."""
+        assert len(unique_ids) == self.frames_in_flight and all(len(u) == COMM_ID_BYTES for u in unique_ids)
+        buf = (C.c_uint8 * (COMM_ID_BYTES * len(unique_ids))).from_buffer_copy(b"".join(unique_ids))
+        _check(lib.rt_pipeline_comm_create(self.handle, buf, world_size, rank))
+
+    def submit(self, width, height, spp, depth, seed=0, spp_first=0, flags=0, out=None, reduce_root=PIPELINE_NO_REDUCE):
+        """Queues one frame; returns its ticket.  `out` (array or address) must stay alive until wait(ticket)."""
+        t = C.c_uint64()
+        _check(lib.rt_pipeline_submit(self.handle, width, height, spp_first, spp, depth, seed, flags, _ptr(out), reduce_root,
+                                      C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        stats = Stats()
+        _check(lib.rt_pipeline_wait(self.handle, ticket, C.byref(stats)))
+        return stats
+
+    def close(self):
+        if getattr(self, "handle", None) and lib is not None:
+            lib.rt_pipeline_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -1,0 +1,283 @@
+// Frames in flight: rt_render calls of DIFFERENT frames overlapped on one GPU.
+//
+// A frame's late bounces are latency-bound: under 1 % of its rays, a handful of waves per launch, each launch as long
+// as its longest walk -- the GPU idles through a tenth of a 64-spp frame and through 40 % of an
+// 8-spp share.  Splitting ONE frame does not help (every part has its own late bounces), a second frame does: its
+// large launches fill the CUs the first frame's late launches leave empty.  A pipeline holds `frames_in_flight`
+// contexts of one device (each its own stream, scene copy and path state) and one host thread per context, because
+// rt_render drives its launches from the host (it reads the bounce's counts back before it sizes the next launch).
+// Frames are dealt to the contexts round-robin and each is rendered by the unchanged rt_render: same bits as a
+// lone call.  Host code only; the reference has no counterpart (Engine::render is one synchronous loop,
+// path_integrator.rs:278-318).
+//
+// Multi-GPU: one communicator per context, and the frames' reduces are issued in SUBMISSION order, one at a time
+// (a worker whose frame is rendered waits for the reduce of every earlier frame) -- every rank submits the same
+// frames in the same order, so at any moment at most one collective is outstanding per rank and it is the same one on
+// every rank, whatever the relative speed of the contexts.
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <set>
+#include <thread>
+
+#include "context.h"
+
+namespace rth {
+const char* get_error();  // host/mesh.cpp: the calling thread's rt_last_error() text
+}
+
+namespace {
+
+struct Job {
+    uint64_t ticket = 0;
+    uint32_t width = 0, height = 0, spp_first = 0, spp_count = 0, depth = 0, flags = 0;
+    uint64_t seed = 0;
+    float* rgb_sum = nullptr;
+    int reduce_root = RT_PIPELINE_NO_REDUCE;
+    uint64_t reduce_seq = 0;  // position among the frames that reduce
+};
+
+struct Done {
+    int rc = RT_OK;
+    std::string error;
+    rt_stats stats{};
+};
+
+struct Slot {
+    rt_ctx* ctx = nullptr;
+    rt_comm* comm = nullptr;
+    std::deque<Job> jobs;
+    std::thread worker;
+};
+
+}  // namespace
+
+struct rt_pipeline {
+    int device = 0;
+    std::vector<Slot> slots;
+    std::mutex m;
+    std::condition_variable cv;  // jobs queued, frames done, reduce turns: all waiters re-check their own condition
+    std::map<uint64_t, Done> done;
+    std::set<uint64_t> pending;  // submitted and not yet waited for
+    uint64_t next_ticket = 0, next_reduce_seq = 0, reduce_turn = 0;
+    bool stop = false;
+};
+
+namespace {
+
+void worker_main(rt_pipeline* p, size_t s) {
+    Slot& slot = p->slots[s];
+    for (;;) {
+        Job j;
+        {
+            std::unique_lock<std::mutex> lk(p->m);
+            p->cv.wait(lk, [&] { return p->stop || !slot.jobs.empty(); });
+            if (slot.jobs.empty()) return;  // stopped and drained
+            j = slot.jobs.front();
+            slot.jobs.pop_front();
+        }
+        Done d;
+        d.rc = rt_render(slot.ctx, j.width, j.height, j.spp_first, j.spp_count, j.depth, j.seed, j.flags, j.rgb_sum, &d.stats);
+        if (d.rc != RT_OK) d.error = rth::get_error();
+        std::unique_lock<std::mutex> lk(p->m);
+        if (j.reduce_root != RT_PIPELINE_NO_REDUCE) {
+            p->cv.wait(lk, [&] { return p->reduce_turn == j.reduce_seq; });
+            lk.unlock();
+            if (d.rc == RT_OK) {  // a frame that failed here leaves the other ranks waiting in theirs: as with rt_render + rt_reduce_accum by hand
+                d.rc = rt_reduce_accum(slot.comm, j.rgb_sum, j.width, j.height, j.reduce_root);
+                if (d.rc != RT_OK) d.error = rth::get_error();
+            }
+            lk.lock();
+            ++p->reduce_turn;
+        }
+        p->done.emplace(j.ticket, std::move(d));
+        p->cv.notify_all();
+    }
+}
+
+void shut_down(rt_pipeline* p) {
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        p->stop = true;
+    }
+    p->cv.notify_all();
+    for (Slot& s : p->slots)
+        if (s.worker.joinable()) s.worker.join();
+    for (Slot& s : p->slots) {
+        if (s.comm) rt_comm_destroy(s.comm);
+        s.comm = nullptr;
+    }
+    for (Slot& s : p->slots) {
+        if (s.ctx) rt_destroy(s.ctx);
+        s.ctx = nullptr;
+    }
+}
+
+bool idle(rt_pipeline* p) {  // caller holds p->m
+    for (const Slot& s : p->slots)
+        if (!s.jobs.empty()) return false;
+    return p->done.size() == p->pending.size();  // every submitted frame is rendered
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_pipeline_create(int device, uint32_t frames_in_flight, rt_pipeline** out) try {
+    if (!out || frames_in_flight < 1 || frames_in_flight > RT_PIPELINE_MAX_FRAMES) {
+        rth::set_error("rt_pipeline_create: frames_in_flight must be 1..%d", RT_PIPELINE_MAX_FRAMES);
+        return RT_ERR_INVALID;
+    }
+    rt_pipeline* p = new rt_pipeline;
+    p->device = device;
+    p->slots.resize(frames_in_flight);
+    for (Slot& s : p->slots) {
+        int rc = rt_create(device, &s.ctx);
+        if (rc != RT_OK) {
+            shut_down(p);
+            delete p;
+            return rc;
+        }
+    }
+    for (size_t s = 0; s < p->slots.size(); ++s) p->slots[s].worker = std::thread(worker_main, p, s);
+    *out = p;
+    return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_pipeline_create");
+}
+
+void rt_pipeline_destroy(rt_pipeline* p) {
+    if (!p) return;
+    shut_down(p);  // renders what is still queued first
+    delete p;
+}
+
+uint32_t rt_pipeline_frames(const rt_pipeline* p) { return p ? (uint32_t)p->slots.size() : 0u; }
+
+rt_ctx* rt_pipeline_context(rt_pipeline* p, uint32_t slot) {
+    if (!p || slot >= p->slots.size()) {
+        rth::set_error("rt_pipeline_context: no such slot");
+        return nullptr;
+    }
+    return p->slots[slot].ctx;
+}
+
+int rt_pipeline_upload_scene(rt_pipeline* p, const rt_scene_flat* scene) try {
+    if (!p || !scene) {
+        rth::set_error("rt_pipeline_upload_scene: null argument");
+        return RT_ERR_INVALID;
+    }
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        if (!idle(p)) {
+            rth::set_error("rt_pipeline_upload_scene: frames are in flight (wait for them first)");
+            return RT_ERR_STATE;
+        }
+    }
+    size_t reusable = 0;
+    for (Slot& s : p->slots) {
+        int rc = rt_upload_scene(s.ctx, scene);
+        if (rc != RT_OK) return rc;
+        reusable += s.ctx->path_state.bytes;
+    }
+    // rt_render sizes a context's path state from the free HBM it finds (40 %): the first context of several would
+    // take most of it.  Share 80 % of what is free now among the contexts instead (192 B per path slot, as there).
+    RT_HIP(hipSetDevice(p->device));
+    size_t free_b = 0, total_b = 0;
+    RT_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double share = (double)(free_b + reusable) * 0.8 / (double)p->slots.size();
+    uint64_t max_paths = (uint64_t)(share / 192.0);
+    if (max_paths < ((uint64_t)1 << 20)) max_paths = (uint64_t)1 << 20;
+    for (Slot& s : p->slots) {
+        int rc = rt_set_max_paths_in_flight(s.ctx, max_paths);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_pipeline_upload_scene");
+}
+
+int rt_pipeline_comm_create(rt_pipeline* p, const uint8_t* ids, int world_size, int rank) try {
+    if (!p || !ids) {
+        rth::set_error("rt_pipeline_comm_create: null argument");
+        return RT_ERR_INVALID;
+    }
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        if (!idle(p)) {
+            rth::set_error("rt_pipeline_comm_create: frames are in flight (wait for them first)");
+            return RT_ERR_STATE;
+        }
+    }
+    for (Slot& s : p->slots)
+        if (s.comm) {
+            rth::set_error("rt_pipeline_comm_create: the pipeline has communicators already");
+            return RT_ERR_STATE;
+        }
+    // slot by slot, in the same order on every rank (each creation is collective)
+    for (size_t s = 0; s < p->slots.size(); ++s) {
+        int rc = rt_comm_create(p->slots[s].ctx, ids + s * RT_COMM_ID_BYTES, world_size, rank, &p->slots[s].comm);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_pipeline_comm_create");
+}
+
+int rt_pipeline_submit(rt_pipeline* p, uint32_t width, uint32_t height, uint32_t spp_first, uint32_t spp_count, uint32_t depth,
+                       uint64_t seed, uint32_t flags, float* rgb_sum, int reduce_root, uint64_t* ticket) try {
+    if (!p || !rgb_sum || !ticket) {
+        rth::set_error("rt_pipeline_submit: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (reduce_root != RT_PIPELINE_NO_REDUCE && !p->slots[0].comm) {
+        rth::set_error("rt_pipeline_submit: a reduce was asked for, but rt_pipeline_comm_create has not been called");
+        return RT_ERR_STATE;
+    }
+    Job j;
+    j.width = width, j.height = height, j.spp_first = spp_first, j.spp_count = spp_count, j.depth = depth, j.flags = flags;
+    j.seed = seed, j.rgb_sum = rgb_sum, j.reduce_root = reduce_root;
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        j.ticket = p->next_ticket;
+        Slot& slot = p->slots[j.ticket % p->slots.size()];
+        if (reduce_root != RT_PIPELINE_NO_REDUCE) j.reduce_seq = p->next_reduce_seq;
+        slot.jobs.push_back(j);
+        p->pending.insert(j.ticket);  // nothing below throws: the counters move only once the job is queued
+        ++p->next_ticket;
+        if (reduce_root != RT_PIPELINE_NO_REDUCE) ++p->next_reduce_seq;
+    }
+    p->cv.notify_all();
+    *ticket = j.ticket;
+    return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_pipeline_submit");
+}
+
+int rt_pipeline_wait(rt_pipeline* p, uint64_t ticket, rt_stats* stats) try {
+    if (!p) {
+        rth::set_error("rt_pipeline_wait: null argument");
+        return RT_ERR_INVALID;
+    }
+    Done d;
+    {
+        std::unique_lock<std::mutex> lk(p->m);
+        if (!p->pending.count(ticket)) {
+            rth::set_error("rt_pipeline_wait: ticket %llu was never handed out or has been waited for", (unsigned long long)ticket);
+            return RT_ERR_INVALID;
+        }
+        p->cv.wait(lk, [&] { return p->done.count(ticket) != 0; });
+        auto it = p->done.find(ticket);
+        d = std::move(it->second);
+        p->done.erase(it);
+        p->pending.erase(ticket);
+    }
+    if (stats) *stats = d.stats;
+    if (d.rc != RT_OK) rth::set_error("%s", d.error.c_str());  // the worker's message, on the caller's thread
+    return d.rc;
+} catch (...) {
+    return rth::on_exception("rt_pipeline_wait");
+}
+
+}  // extern "C"
