@@ -9,7 +9,11 @@ workload "render" (default): BASELINE.json configs[2] -- full path tracing (diff
     (rank r renders sample_shard(64, N, r) of every pixel) and the radiance accumulators are summed to
     rank 0 with one RCCL reduce over xGMI through the C ABI (rt_reduce_accum), inside the timed region:
     STRONG scaling, the BASELINE metric "ms/frame @1080p 64 spp at 1/2/4/8 GPUs".  --scaling weak gives
-    every rank its own 64 samples instead (the frame gains samples).
+    every rank its own 64 samples instead (the frame gains samples).  The K timed frames go through a frame pipeline
+    (rt_pipeline_*, --frames-in-flight, default 2 at >= 32 spp per rank and 4 below): whole frames overlap on the GPU,
+    each rendered -- and reduced -- by the same calls as a lone frame, so `value` and `ms_per_step` are THROUGHPUT
+    figures; the latency of a lone frame (`ms_frame_alone`) and the kernel time the roofline uses are measured on frames
+    rendered one at a time directly after the timed region (--frames-in-flight 1 times those instead).
 workload "config5": BASELINE.json configs[4]'s scene -- a plane and 10 subdivided tetrahedra, each its OWN
     mesh and BVH (10.5 M triangles, 1.1 GB of geometry: beyond the 256 MiB Infinity Cache); --instanced
     shares one BVH instead.  --width 3840 for 4K.  Used for the cache-resident / out-of-cache comparison.
@@ -64,6 +68,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
     ap.add_argument("--max-paths", type=int, default=0, help="paths in flight per batch (0 = library default)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames rendered at once in the timed region (rt_pipeline_*); 1 = one synchronous rt_render per step; "
+                         "0 = 2 at >= 32 spp per rank, 4 below")
     return ap.parse_args()
 
 
@@ -101,10 +108,28 @@ def main():
     else:
         desc = scenes.path_scene(levels=args.levels)
     scene = rt.Scene(desc)
-    ctx = rt.Context(local_rank)
-    ctx.upload(scene)
-    if args.max_paths:
-        ctx.set_max_paths_in_flight(args.max_paths)
+    pipe, n_flight = None, 1
+    if args.workload != "trace":
+        from ray_tracing_amd.distributed import sample_shard
+        if args.scaling == "strong":  # the 64-spp frame, sharded by global sample index
+            spp_first, spp_count = sample_shard(args.spp, world, rank)
+        else:                          # every rank its own args.spp samples
+            spp_first, spp_count = rank * args.spp, args.spp
+        n_flight = args.frames_in_flight or (2 if args.spp // world >= 32 else 4)  # the same on every rank
+        if args.torch_reduce:
+            n_flight = 1
+    if n_flight > 1:  # one context per frame in flight; slot 0's context also serves the untimed passes
+        pipe = rt.FramePipeline(local_rank, n_flight)
+        pipe.upload(scene)
+        ctx = pipe.context(0)
+        if args.max_paths:
+            for s in range(n_flight):
+                pipe.context(s).set_max_paths_in_flight(args.max_paths)
+    else:
+        ctx = rt.Context(local_rank)
+        ctx.upload(scene)
+        if args.max_paths:
+            ctx.set_max_paths_in_flight(args.max_paths)
     setup_s = time.time() - t_setup
     n_tris = scene.flat.n_tris
 
@@ -163,13 +188,9 @@ def main():
                       rays_closest=n, rays_shadow=ns)
         workload = f"configs[1]: primary+shadow rays, {n_tris}-triangle subdivided tetrahedron, {width}x{height}, 1 spp"
     else:
-        from ray_tracing_amd.distributed import sample_shard
-        acc = torch.zeros(height, width, 3, dtype=torch.float32, device=dev)
+        accs = [torch.zeros(height, width, 3, dtype=torch.float32, device=dev) for _ in range(n_flight)]
+        acc = accs[0]
         torch.cuda.synchronize()
-        if args.scaling == "strong":  # the 64-spp frame, sharded by global sample index
-            spp_first, spp_count = sample_shard(args.spp, world, rank)
-        else:                          # every rank its own args.spp samples
-            spp_first, spp_count = rank * args.spp, args.spp
         # the accumulator reduce: RCCL through the C ABI on the library's own stream (ordered behind rt_render
         # without a host sync); torch.distributed only carries the unique id and the barriers
         comm, reduce_kind = None, "none"
@@ -188,18 +209,31 @@ def main():
                 ok = torch.tensor([can], device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) == 1:
-                    uid = torch.tensor(list(my_id), dtype=torch.uint8, device=dev)  # rank 0's id is the communicator's
+                    # rank 0's ids are the communicators': one per frame in flight
+                    ids = my_id + b"".join(rt.comm_unique_id() for _ in range(n_flight - 1))
+                    uid = torch.tensor(list(ids), dtype=torch.uint8, device=dev)
                     dist.broadcast(uid, src=0)
+                    ids = bytes(uid.cpu().tolist())
                     try:
-                        comm = rt.Comm(ctx, bytes(uid.cpu().tolist()), world, rank)
+                        if pipe is not None:
+                            pipe.comm_create([ids[128 * s:128 * (s + 1)] for s in range(n_flight)], world, rank)
+                            comm = pipe
+                        else:
+                            comm = rt.Comm(ctx, ids, world, rank)
                         reduce_kind = "rt_reduce_accum (RCCL, C ABI)"
                     except rt.RtError as e:  # plumbing fallback for the collective only; labelled in the output
                         print(f"bench: rt_comm_create failed on rank {rank} ({e}); reducing with torch.distributed", file=sys.stderr)
             ok = torch.tensor([1 if (comm is not None or args.torch_reduce) else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and comm is not None:  # some rank fell back: all ranks must
-                comm.close()
+            if int(ok.item()) == 0:  # some rank fell back: all ranks must, to one synchronous frame per step
+                if comm is not None and comm is not pipe:
+                    comm.close()
                 comm, reduce_kind = None, "torch.distributed"
+                if pipe is not None:
+                    ctx = rt.Context(local_rank)
+                    ctx.upload(scene)
+                    pipe.close()
+                    pipe, n_flight = None, 1
         # untimed counting passes (also the warm-up of every kernel): the fetches the timed kernels perform
         # (root-box skip and top-level cull active) price the roofline; the reference's visits are listed beside
         _, st_count = ctx.render(width, height, spp_count, args.depth, args.seed, spp_first,
@@ -210,31 +244,66 @@ def main():
 
         ext_ms, ext_launches, mix_ms, mix_launches = [], [], [], []
 
-        def step(record, all_stages=False):
+        def record_stats(st):  # k_extend is timed by HIP events on the library's stream in every render call
+            ext_ms.append(st.ms_extend)
+            ext_launches.append(st.launches_extend)
+            mix_ms.append(st.ms_tail)  # mixed (shadow + next bounce) and tail launches: timed the same way
+            mix_launches.append(st.launches_tail)
+
+        def step(record, all_stages=False, reduce=True):
             _, st = ctx.render(width, height, spp_count, args.depth, args.seed, spp_first,
                                flags=rt.api.RENDER_TIME_STAGES if all_stages else 0, out=acc.data_ptr())
-            if comm is not None:
+            if not reduce or pipe is not None:  # (a pipeline's communicators reduce its own frames only)
+                pass
+            elif comm is not None:
                 comm.reduce_accum(acc.data_ptr(), width, height, 0)  # returns when the sum is complete
             elif use_dist:
                 dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
                 torch.cuda.synchronize()  # the next render overwrites acc on the library's stream
             last["st"] = st
-            if record:  # k_extend is timed by HIP events on the library's stream in every render call
-                ext_ms.append(st.ms_extend)
-                ext_launches.append(st.launches_extend)
-                mix_ms.append(st.ms_tail)  # mixed (shadow + next bounce) and tail launches: timed the same way
-                mix_launches.append(st.launches_tail)
+            if record:
+                record_stats(st)
 
-        for _ in range(args.warmup):
-            step(False)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(True)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        def steps_in_flight(n, record):
+            """n frames through the pipeline: all queued at once, up to n_flight of them on the GPU at any time; frame k
+            renders into accumulator k % n_flight (the slot's own), followed by its reduce.  Returns when all are done."""
+            root = 0 if comm is not None else rt.api.PIPELINE_NO_REDUCE
+            tickets = [pipe.submit(width, height, spp_count, args.depth, args.seed, spp_first,
+                                   out=accs[k % n_flight].data_ptr(), reduce_root=root) for k in range(n)]
+            for t in tickets:
+                st = pipe.wait(t)
+                if record:
+                    record_stats(st)
+
+        if pipe is not None:
+            steps_in_flight(args.warmup, False)
+            barrier()
+            t0 = time.perf_counter()
+            steps_in_flight(args.steps, True)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            # with frames in flight an event pair on one stream also spans the other frames' kernels: the kernel times the
+            # roofline uses, and the latency of a lone frame, come from frames rendered one at a time right here
+            in_flight = {"kernel_ms_extend": float(np.mean(ext_ms)) / max(1, int(np.mean(ext_launches))) if ext_ms else None,
+                         "kernel_ms_mixed": float(np.mean(mix_ms)) / max(1, int(np.mean(mix_launches))) if mix_ms else None}
+            ext_ms, ext_launches, mix_ms, mix_launches = [], [], [], []
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step(True, reduce=False)
+            ms_frame_alone = (time.perf_counter() - t1) / 3 * 1e3
+        else:
+            for _ in range(args.warmup):
+                step(False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(True)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            in_flight, ms_frame_alone = None, elapsed / args.steps * 1e3
         # one more (untimed) step with HIP events around every stage, for the breakdown in `detail`
-        step(False, all_stages=True)
+        step(False, all_stages=True, reduce=False)
         st = last["st"]
         rays_per_step = st.rays_closest + st.rays_shadow - st.rays_shadow_skipped  # rays actually traced
 
@@ -275,7 +344,10 @@ def main():
                       n_int_reference=st_ref.nodes_visited / max(1, st_ref.rays_closest),
                       rays_closest=int(st.rays_closest), rays_shadow=int(st.rays_shadow),
                       rays_shadow_not_traced=int(st.rays_shadow_skipped),
-                      iterations=int(st.iterations), spp_this_rank=int(spp_count), reduce=reduce_kind)
+                      iterations=int(st.iterations), spp_this_rank=int(spp_count), reduce=reduce_kind,
+                      frames_in_flight=int(n_flight), ms_frame_alone=ms_frame_alone,
+                      separate_hw_queues=(int(pipe.separate_queues) if pipe is not None else None),
+                      kernel_ms_with_frames_in_flight=in_flight)
         if args.workload == "config5":
             workload = (f"configs[4] scene: plane + {args.copies} subdivided tetrahedra, "
                         f"{'instances of one BVH' if args.instanced else 'each its own mesh and BVH'}, {n_tris} triangles, "
@@ -283,8 +355,11 @@ def main():
         else:
             workload = (f"configs[2]: path tracing diffuse+dielectric, area-light NEE/MIS, RR, {n_tris} triangles, "
                         f"{width}x{height}, {args.spp} spp, depth {args.depth}")
-        if comm is not None:
+        if comm is not None and comm is not pipe:
             comm.close()
+        if pipe is not None:
+            ctx = None
+            pipe.close()
 
     # max over ranks of the timed region
     if use_dist:
@@ -331,7 +406,14 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "seed": args.seed,
                        "parallelism": (f"sample-sharded x{world} ({args.scaling}), {result.get('reduce', 'none')}" if world > 1 else "1 GPU"),
-                       "ms_per_frame": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1),
+                       "ms_per_frame": round(ms_per_step, 3),
+                       **({"frames_in_flight": result["frames_in_flight"],
+                           "ms_frame_alone": round(result["ms_frame_alone"], 3),
+                           "frames_in_flight_note": "ms_per_step / ms_per_frame / value are throughput over the K timed frames, up to "
+                                                    "frames_in_flight of them on the GPU at once (rt_pipeline_*); ms_frame_alone is "
+                                                    "one frame rendered alone" + (", without its reduce" if world > 1 else "")}
+                          if result.get("frames_in_flight", 1) > 1 else {}),
+                       "scene_setup_s": round(setup_s, 1),
                        "geometry_bytes": int(geom_bytes), "build": rt.api.build_id()},
             "roofline": {"bound": "hbm", "achieved": round(roof_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(roof_achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -342,13 +424,18 @@ def main():
                          "traffic_detail": traffic_detail,
                          "stream_copy_GBs": round(stream_copy, 1),
                          "kernel": result["kernel"], "kernel_ms": round(result["kernel_ms"], 4),
+                         **({"kernel_ms_note": "launch duration with ONE frame on the GPU (3 frames rendered one at a time right after the "
+                                               "timed region; bench.py --frames-in-flight 1 times exactly those, and the committed rocprofv3 "
+                                               "summary is of that command): with frames in flight the launches of different frames share "
+                                               "the CUs, and an event pair on one stream spans both (detail.kernel_ms_with_frames_in_flight)"}
+                            if result.get("frames_in_flight", 1) > 1 else {}),
                          "alg_bytes_per_launch": int(result["alg_bytes"]),
                          "alg_bytes_note": "48 + 64 N_int + 40 N_tri per ray with N_int / N_tri counted on the TIMED kernel's own fetches "
                                            "(root-box skip and top-level cull active)",
                          "n_int_per_ray": round(result["n_int_mean"], 3), "n_tri_per_ray": round(result["n_tri_mean"], 3),
                          **({"traversal_kernels": result["kernels"]} if "kernels" in result else {})},
             "detail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in result.items()
-                       if k not in ("kernel", "alg_bytes", "kernels")},
+                       if k not in ("kernel", "alg_bytes", "kernels", "frames_in_flight")},
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, desc, scene, width, height)

@@ -360,6 +360,12 @@ int rt_pipeline_create(int device, uint32_t frames_in_flight, rt_pipeline** out)
 /* Renders what is still queued, then releases the communicators and the contexts. */
 void rt_pipeline_destroy(rt_pipeline* pipe);
 uint32_t rt_pipeline_frames(const rt_pipeline* pipe);
+/* Streams of one process share a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and work of two streams on ONE
+   hardware queue runs in order, not side by side.  rt_pipeline_create tests its contexts' streams against each other
+   (a 2 ms spin kernel on one, an empty kernel on the other) and replaces a stream that had to wait.  This is the number
+   of slots seen to run beside all slots before them (slot 0 included): frames_in_flight when every frame in flight has a
+   hardware queue of its own, less when the process has more busy streams than the GPU has queues. */
+uint32_t rt_pipeline_separate_queues(const rt_pipeline* pipe);
 /* The context of one slot, borrowed: for settings (rt_set_visit_count_mode, ...) and for plain rt_render calls
    while no frame is in flight. */
 rt_ctx* rt_pipeline_context(rt_pipeline* pipe, uint32_t slot);

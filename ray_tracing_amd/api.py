@@ -126,7 +126,7 @@ EXPORTS = ["rt_mesh_create", "rt_mesh_read_stl", "rt_mesh_loop_subdivide", "rt_m
            "rt_scene_view", "rt_scene_destroy", "rt_tonemap_u8", "rt_write_ppm", "rt_create", "rt_destroy",
            "rt_upload_scene", "rt_initial_medium", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render", "rt_ray_colour",
            "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy", "rt_reduce_accum",
-           "rt_pipeline_create", "rt_pipeline_destroy", "rt_pipeline_frames", "rt_pipeline_context",
+           "rt_pipeline_create", "rt_pipeline_destroy", "rt_pipeline_frames", "rt_pipeline_separate_queues", "rt_pipeline_context",
            "rt_pipeline_upload_scene", "rt_pipeline_comm_create", "rt_pipeline_submit", "rt_pipeline_wait",
            "rt_set_max_paths_in_flight", "rt_set_visit_count_mode", "rt_last_kernel_ms", "rt_stream", "rt_last_error", "rt_version"]
 
@@ -184,6 +184,8 @@ lib.rt_pipeline_destroy.argtypes = [C.c_void_p]
 lib.rt_pipeline_destroy.restype = None
 lib.rt_pipeline_frames.argtypes = [C.c_void_p]
 lib.rt_pipeline_frames.restype = C.c_uint32
+lib.rt_pipeline_separate_queues.argtypes = [C.c_void_p]
+lib.rt_pipeline_separate_queues.restype = C.c_uint32
 lib.rt_pipeline_context.argtypes = [C.c_void_p, C.c_uint32]
 lib.rt_pipeline_context.restype = C.c_void_p
 lib.rt_pipeline_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneFlat)]
@@ -557,6 +559,7 @@ class FramePipeline:
         _check(lib.rt_pipeline_create(C.c_int(device), frames_in_flight, C.byref(h)))
         self.handle = h
         self.frames_in_flight = lib.rt_pipeline_frames(h)
+        self.separate_queues = lib.rt_pipeline_separate_queues(h)  # slots whose streams were seen to run side by side
 
     def upload(self, scene):
         flat = scene.flat if isinstance(scene, Scene) else scene

@@ -10,11 +10,19 @@
 // lone call.  Host code only; the reference has no counterpart (Engine::render is one synchronous loop,
 // path_integrator.rs:278-318).
 //
+// Pacing: frames that start together stay together (equal work, and the reduce order below re-aligns them frame after
+// frame), and two frames in the SAME phase gain nothing from each other -- their large launches and their late launches
+// coincide (bench.py, one rank with reduces: 52.4 ms per frame, as without a pipeline, against 49.5).  A worker therefore
+// starts a frame no earlier than RT_PIPELINE_PACE (default 0.8) x latency / frames_in_flight after the previous start of
+// any worker, latency being the running mean of the frames' own render times in the pipeline.
+//
 // Multi-GPU: one communicator per context, and the frames' reduces are issued in SUBMISSION order, one at a time
 // (a worker whose frame is rendered waits for the reduce of every earlier frame) -- every rank submits the same
 // frames in the same order, so at any moment at most one collective is outstanding per rank and it is the same one on
 // every rank, whatever the relative speed of the contexts.
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -62,6 +70,11 @@ struct rt_pipeline {
     std::set<uint64_t> pending;  // submitted and not yet waited for
     uint64_t next_ticket = 0, next_reduce_seq = 0, reduce_turn = 0;
     bool stop = false;
+    uint32_t separate = 0;  // slots whose stream was seen to run beside those of all slots before it (slot 0 counts)
+    // pacing (see the top of the file)
+    double pace = 0.8;
+    double latency_s = 0.0;  // running mean of rt_render's duration inside the pipeline; 0 = none measured yet
+    std::chrono::steady_clock::time_point last_start{};
 };
 
 namespace {
@@ -76,11 +89,21 @@ void worker_main(rt_pipeline* p, size_t s) {
             if (slot.jobs.empty()) return;  // stopped and drained
             j = slot.jobs.front();
             slot.jobs.pop_front();
+            while (!p->stop && p->latency_s > 0.0 && p->pace > 0.0) {  // re-evaluated after every wake-up: another worker may have started
+                const auto earliest = p->last_start + std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                                                          std::chrono::duration<double>(p->pace * p->latency_s / (double)p->slots.size()));
+                if (std::chrono::steady_clock::now() >= earliest) break;
+                p->cv.wait_until(lk, earliest);
+            }
+            p->last_start = std::chrono::steady_clock::now();
         }
         Done d;
+        const auto t_start = std::chrono::steady_clock::now();
         d.rc = rt_render(slot.ctx, j.width, j.height, j.spp_first, j.spp_count, j.depth, j.seed, j.flags, j.rgb_sum, &d.stats);
         if (d.rc != RT_OK) d.error = rth::get_error();
+        const double took = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         std::unique_lock<std::mutex> lk(p->m);
+        p->latency_s = p->latency_s > 0.0 ? 0.75 * p->latency_s + 0.25 * took : took;
         if (j.reduce_root != RT_PIPELINE_NO_REDUCE) {
             p->cv.wait(lk, [&] { return p->reduce_turn == j.reduce_seq; });
             lk.unlock();
@@ -94,6 +117,75 @@ void worker_main(rt_pipeline* p, size_t s) {
         p->done.emplace(j.ticket, std::move(d));
         p->cv.notify_all();
     }
+}
+
+// ---- streams that really run side by side
+// HIP multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), a new stream joining
+// the least-shared queue of its priority -- which can be the queue of the stream created just before it, and work of two
+// streams on one hardware queue runs strictly in order: bench.py's multi-GPU path (PyTorch and RCCL hold six streams by
+// then) had both contexts on one queue and no overlap at all.  Priorities would separate them (one queue pool per
+// priority) but cost more than a millisecond per frame.  So the slots' streams are TESTED: a 2 ms spin on one, an empty
+// kernel on the other -- finished while the spin still runs, or the two share a queue and the stream is replaced (the
+// rejects stay alive until the end, so that the next stream goes elsewhere).
+__global__ void k_spin(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+    }
+}
+__global__ void k_nop() {}
+
+int runs_beside(hipStream_t busy, hipStream_t other, hipEvent_t e_busy, hipEvent_t e_other, unsigned long long ticks, bool* out) {
+    k_spin<<<1, 64, 0, busy>>>(ticks);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(e_busy, busy));
+    k_nop<<<1, 64, 0, other>>>();
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(e_other, other));
+    RT_HIP(hipEventSynchronize(e_other));
+    const hipError_t q = hipEventQuery(e_busy);  // still spinning: `other` did not have to wait for it
+    if (q != hipSuccess && q != hipErrorNotReady) RT_HIP(q);
+    (void)hipGetLastError();
+    *out = q == hipErrorNotReady;
+    RT_HIP(hipEventSynchronize(e_busy));
+    return RT_OK;
+}
+
+int separate_queues(rt_pipeline* p) {
+    p->separate = 1;
+    if (p->slots.size() < 2) return RT_OK;
+    RT_HIP(hipSetDevice(p->device));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, p->device) != hipSuccess || khz <= 0) {
+        (void)hipGetLastError();
+        khz = 100000;  // the constant 100 MHz counter of gfx9
+    }
+    const unsigned long long ticks = (unsigned long long)khz * 2ull;  // 2 ms
+    hipEvent_t ea = nullptr, eb = nullptr;
+    RT_HIP(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+    RT_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    std::vector<hipStream_t> rejects;
+    int rc = RT_OK;
+    for (size_t k = 1; k < p->slots.size() && rc == RT_OK; ++k) {
+        bool ok = false;
+        for (int attempt = 0; attempt < 12 && rc == RT_OK; ++attempt) {
+            ok = true;
+            for (size_t j = 0; j < k && ok && rc == RT_OK; ++j)
+                rc = runs_beside(p->slots[j].ctx->stream, p->slots[k].ctx->stream, ea, eb, ticks, &ok);
+            if (ok || rc != RT_OK) break;
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            rejects.push_back(p->slots[k].ctx->stream);
+            p->slots[k].ctx->stream = st;
+        }
+        if (ok && rc == RT_OK) ++p->separate;  // else: more slots than free hardware queues -- the slot shares one
+    }
+    for (hipStream_t st : rejects) (void)hipStreamDestroy(st);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    return rc;
 }
 
 void shut_down(rt_pipeline* p) {
@@ -131,6 +223,7 @@ int rt_pipeline_create(int device, uint32_t frames_in_flight, rt_pipeline** out)
     }
     rt_pipeline* p = new rt_pipeline;
     p->device = device;
+    if (const char* e = getenv("RT_PIPELINE_PACE")) p->pace = atof(e);
     p->slots.resize(frames_in_flight);
     for (Slot& s : p->slots) {
         int rc = rt_create(device, &s.ctx);
@@ -139,6 +232,12 @@ int rt_pipeline_create(int device, uint32_t frames_in_flight, rt_pipeline** out)
             delete p;
             return rc;
         }
+    }
+    int rc = separate_queues(p);
+    if (rc != RT_OK) {
+        shut_down(p);
+        delete p;
+        return rc;
     }
     for (size_t s = 0; s < p->slots.size(); ++s) p->slots[s].worker = std::thread(worker_main, p, s);
     *out = p;
@@ -154,6 +253,8 @@ void rt_pipeline_destroy(rt_pipeline* p) {
 }
 
 uint32_t rt_pipeline_frames(const rt_pipeline* p) { return p ? (uint32_t)p->slots.size() : 0u; }
+
+uint32_t rt_pipeline_separate_queues(const rt_pipeline* p) { return p ? p->separate : 0u; }
 
 rt_ctx* rt_pipeline_context(rt_pipeline* p, uint32_t slot) {
     if (!p || slot >= p->slots.size()) {

@@ -1,7 +1,9 @@
-"""Probe: frame THROUGHPUT when whole frames are pipelined over two contexts (two streams, two host threads), each
-started a fraction of a frame after the one before, so that the latency-bound late bounces of one frame run beside the large launches
-of the next.  Prints ms per frame of one context alone and of the staggered pair."""
-import os, sys, time, threading
+"""Frame THROUGHPUT with frames in flight (rt_pipeline_*): ms per frame of one frame at a time against F frames at once.
+
+    python scripts/pipeline_probe.py SPP FRAMES F [comm|reduce]
+
+comm: create the slots' communicators (world size 1) but do not reduce; reduce: reduce every frame onto rank 0 too."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ray_tracing_amd as rt
@@ -9,39 +11,51 @@ from ray_tracing_amd import scenes
 
 w, h, depth = 1920, 1080, 16
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-n_ctx = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-stagger_ms = float(sys.argv[4]) if len(sys.argv) > 4 else -1.0  # < 0: one frame's time / n_ctx
-scene = rt.Scene(scenes.path_scene(levels=9))
-ctxs = [rt.Context(0) for _ in range(n_ctx)]
-for c in ctxs:
-    c.upload(scene)
-accs = [torch.zeros(h, w, 3, device="cuda") for _ in range(n_ctx)]
-
-
-def run(i, n, delay):
-    if delay > 0:
-        time.sleep(delay)
-    for k in range(n):
-        ctxs[i].render(w, h, spp, depth, k, 0, out=accs[i].data_ptr())
-
-
-for i in range(n_ctx):
-    run(i, 2, 0)
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+n_flight = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+mode = sys.argv[4] if len(sys.argv) > 4 else ""
+extra = sys.argv[5] if len(sys.argv) > 5 else ""  # torchdist / torchdist-lazy: a torch.distributed NCCL group beside it
+if extra.startswith("torchdist"):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    if extra == "torchdist":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    if extra not in ("torchdist-nocoll", "torchdist-after"):
+        dist.barrier()
+        torch.cuda.synchronize()
+pipe = rt.FramePipeline(0, n_flight)
+pipe.upload(rt.Scene(scenes.path_scene(levels=9)))
+if extra == "torchdist-after":  # bench.py's order: collectives of the torch group once the contexts exist
+    x = torch.ones(1, device="cuda")
+    dist.all_reduce(x)
+    dist.broadcast(x, src=0)
+    dist.barrier()
+    torch.cuda.synchronize()
+if mode in ("comm", "reduce"):
+    pipe.comm_create([rt.comm_unique_id() for _ in range(n_flight)], 1, 0)
+root = 0 if mode == "reduce" else rt.api.PIPELINE_NO_REDUCE
+accs = [torch.zeros(h, w, 3, device="cuda") for _ in range(n_flight)]
 torch.cuda.synchronize()
+
+
+def run(n):
+    for t in [pipe.submit(w, h, spp, depth, k, out=accs[k % n_flight].data_ptr(), reduce_root=root) for k in range(n)]:
+        pipe.wait(t)
+
+
+run(2 * n_flight)
+ctx = pipe.context(0)
 t0 = time.perf_counter()
-run(0, frames, 0)
-torch.cuda.synchronize()
-alone = (time.perf_counter() - t0) / frames
-if stagger_ms < 0:
-    stagger_ms = alone * 1e3 / n_ctx
-ts = [threading.Thread(target=run, args=(i, frames, i * stagger_ms * 1e-3)) for i in range(n_ctx)]
+for k in range(4):
+    ctx.render(w, h, spp, depth, k, out=accs[0].data_ptr())
+alone = (time.perf_counter() - t0) / 4
 t0 = time.perf_counter()
-for t in ts:
-    t.start()
-for t in ts:
-    t.join()
-torch.cuda.synchronize()
-pair = (time.perf_counter() - t0) / (n_ctx * frames)
-print(f"{spp} spp: one context {alone*1e3:.2f} ms/frame; {n_ctx} contexts staggered by {stagger_ms:.1f} ms: "
-      f"{pair*1e3:.2f} ms/frame over {n_ctx*frames} frames", flush=True)
+run(frames)
+flight = (time.perf_counter() - t0) / frames
+print(extra, end=" ")
+print(f"{spp} spp: one frame at a time {alone*1e3:.2f} ms/frame; {n_flight} in flight{' + ' + mode if mode else ''}: "
+      f"{flight*1e3:.2f} ms/frame over {frames} frames", flush=True)
+pipe.close()
