@@ -6,7 +6,13 @@ import torch
 import ray_tracing_amd as rt
 from ray_tracing_amd import scenes
 
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""  # substring of the config names to run (default: all)
+
+
 def run(name, desc, w, spp, depth=16, reps=2, flight=2, frames=8):
+    if ONLY not in name:
+        return
+    desc = desc()
     t0 = time.time(); scene = rt.Scene(desc); t_build = time.time() - t0
     pipe = rt.FramePipeline(0, flight); pipe.upload(scene)
     ctx = pipe.context(0)
@@ -33,12 +39,12 @@ def run(name, desc, w, spp, depth=16, reps=2, flight=2, frames=8):
     ctx = None
     pipe.close()
 
-run("config 1 volumetric sphere", scenes.volumetric_sphere(), 400, 256)
-run("config 3 path tracing", scenes.path_scene(levels=9), 1920, 64)
-run("config 4 + homogeneous medium", scenes.path_scene(levels=9, medium=True, sigma_s=0.02), 1920, 64)
-run("config 2 scene, path traced", scenes.tetrahedron_scene(levels=9), 1920, 64)
-run("config 5 instanced (one BVH x10)", scenes.multi_mesh_scene(levels=9, copies=10), 1920, 64)
-run("config 5 ten distinct meshes", scenes.multi_mesh_scene(levels=9, copies=10, distinct=True), 1920, 64)
-run("config 5 instanced, 3840x2160", scenes.multi_mesh_scene(levels=9, copies=10), 3840, 64, reps=1, frames=4)
-run("config 5 distinct, 3840x2160", scenes.multi_mesh_scene(levels=9, copies=10, distinct=True), 3840, 64, reps=1, frames=4)
-run("config 5 distinct, 4K, 256 spp", scenes.multi_mesh_scene(levels=9, copies=10, distinct=True), 3840, 256, reps=1, frames=4)
+run("config 1 volumetric sphere", lambda: scenes.volumetric_sphere(), 400, 256)
+run("config 3 path tracing", lambda: scenes.path_scene(levels=9), 1920, 64)
+run("config 4 + homogeneous medium", lambda: scenes.path_scene(levels=9, medium=True, sigma_s=0.02), 1920, 64)
+run("config 2 scene, path traced", lambda: scenes.tetrahedron_scene(levels=9), 1920, 64)
+run("config 5 instanced (one BVH x10)", lambda: scenes.multi_mesh_scene(levels=9, copies=10), 1920, 64)
+run("config 5 ten distinct meshes", lambda: scenes.multi_mesh_scene(levels=9, copies=10, distinct=True), 1920, 64)
+run("config 5 instanced, 3840x2160", lambda: scenes.multi_mesh_scene(levels=9, copies=10), 3840, 64, reps=1, frames=4)
+run("config 5 distinct, 3840x2160", lambda: scenes.multi_mesh_scene(levels=9, copies=10, distinct=True), 3840, 64, reps=1, frames=4)
+run("config 5 distinct, 4K, 256 spp", lambda: scenes.multi_mesh_scene(levels=9, copies=10, distinct=True), 3840, 256, reps=1, frames=4)
