@@ -387,6 +387,22 @@ int rt_pipeline_submit(rt_pipeline* pipe, uint32_t width, uint32_t height, uint3
    Every ticket is waited for exactly once. */
 int rt_pipeline_wait(rt_pipeline* pipe, uint64_t ticket, rt_stats* stats);
 
+/* The same pipeline with the two per-frame steps supplied by the caller (no counterpart in the reference): `render`
+   runs on the slot's worker thread with the slot's context -- any sequence of calls on it, e.g. rt_ray_colour for
+   frames of caller rays, or rt_render followed by the host's own kernels on rt_stream(ctx) -- and `reduce`, if the
+   frame was submitted with reduce != 0, afterwards, in submission order and one frame at a time across the slots (the
+   guarantee rt_pipeline_submit's reduces have; it is what lets every rank of a multi-GPU job pair its collectives).
+   Both return RT_OK or an RT_ERR_* status, which rt_pipeline_wait hands back.  device < 0: no contexts (ctx is NULL in
+   the hooks), the frames are the caller's own host work -- used by the CPU test of the ordering over gloo
+   (tests/test_pipeline_order_cpu.py). */
+typedef struct rt_pipeline_hooks {
+    int (*render)(void* user, rt_ctx* ctx, uint32_t slot, uint64_t ticket);
+    int (*reduce)(void* user, rt_ctx* ctx, uint32_t slot, uint64_t ticket); /* may be NULL */
+    void* user;
+} rt_pipeline_hooks;
+int rt_pipeline_create_hooked(int device, uint32_t frames_in_flight, const rt_pipeline_hooks* hooks, rt_pipeline** out);
+int rt_pipeline_submit_hooked(rt_pipeline* pipe, int reduce, uint64_t* ticket);
+
 /* Engine::ray_colour (path_integrator.rs:138-276, the crate's public per-ray entry) in batch form: rgb_sum[3k..] =
    sum over the samples [spp_first, spp_first + spp_count) of ray_colour(ray k, depth).  Ray k is taken as it is (the
    reference's callers pass Camera::ray's normalised direction); the random numbers of (ray k, sample s) are those

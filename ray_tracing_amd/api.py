@@ -128,6 +128,7 @@ EXPORTS = ["rt_mesh_create", "rt_mesh_read_stl", "rt_mesh_loop_subdivide", "rt_m
            "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy", "rt_reduce_accum",
            "rt_pipeline_create", "rt_pipeline_destroy", "rt_pipeline_frames", "rt_pipeline_separate_queues", "rt_pipeline_context",
            "rt_pipeline_upload_scene", "rt_pipeline_comm_create", "rt_pipeline_submit", "rt_pipeline_wait",
+           "rt_pipeline_create_hooked", "rt_pipeline_submit_hooked",
            "rt_set_max_paths_in_flight", "rt_set_visit_count_mode", "rt_last_kernel_ms", "rt_stream", "rt_last_error", "rt_version"]
 
 if not os.path.exists(LIB_PATH):
@@ -193,6 +194,15 @@ lib.rt_pipeline_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int
 lib.rt_pipeline_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                    C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
 lib.rt_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Stats)]
+PIPELINE_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64)  # (user, ctx, slot, ticket) -> status
+
+
+class PipelineHooks(C.Structure):
+    _fields_ = [("render", PIPELINE_HOOK), ("reduce", PIPELINE_HOOK), ("user", C.c_void_p)]
+
+
+lib.rt_pipeline_create_hooked.argtypes = [C.c_int, C.c_uint32, C.POINTER(PipelineHooks), C.POINTER(C.c_void_p)]
+lib.rt_pipeline_submit_hooked.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
 lib.rt_set_max_paths_in_flight.argtypes = [C.c_void_p, C.c_uint64]
 lib.rt_set_visit_count_mode.argtypes = [C.c_void_p, C.c_uint32]
 
@@ -554,9 +564,24 @@ class Comm:
 class FramePipeline:
     """rt_pipeline: up to `frames_in_flight` frames rendered at once on one GPU, each by the unchanged rt_render."""
 
-    def __init__(self, device=0, frames_in_flight=2):
+    def __init__(self, device=0, frames_in_flight=2, render=None, reduce=None):
+        """render / reduce: hooks (ctx_address, slot, ticket) -> status for rt_pipeline_create_hooked; device < 0 with
+        hooks runs them without a GPU context (ctx_address is None)."""
         h = C.c_void_p()
-        _check(lib.rt_pipeline_create(C.c_int(device), frames_in_flight, C.byref(h)))
+        if render is None:
+            _check(lib.rt_pipeline_create(C.c_int(device), frames_in_flight, C.byref(h)))
+        else:
+            def wrap(fn):
+                def hook(_user, ctx, slot, ticket):
+                    try:
+                        return int(fn(ctx, slot, ticket) or 0)
+                    except Exception:  # nothing may unwind into the worker thread
+                        import traceback
+                        traceback.print_exc()
+                        return -1
+                return PIPELINE_HOOK(hook)
+            self._hooks = PipelineHooks(wrap(render), wrap(reduce) if reduce is not None else PIPELINE_HOOK(0), None)
+            _check(lib.rt_pipeline_create_hooked(C.c_int(device), frames_in_flight, C.byref(self._hooks), C.byref(h)))
         self.handle = h
         self.frames_in_flight = lib.rt_pipeline_frames(h)
         self.separate_queues = lib.rt_pipeline_separate_queues(h)  # slots whose streams were seen to run side by side
@@ -583,6 +608,11 @@ class FramePipeline:
         t = C.c_uint64()
         _check(lib.rt_pipeline_submit(self.handle, width, height, spp_first, spp, depth, seed, flags, _ptr(out), reduce_root,
                                       C.byref(t)))
+        return t.value
+
+    def submit_hooked(self, reduce=False):
+        t = C.c_uint64()
+        _check(lib.rt_pipeline_submit_hooked(self.handle, int(bool(reduce)), C.byref(t)))
         return t.value
 
     def wait(self, ticket):

@@ -70,6 +70,8 @@ struct rt_pipeline {
     std::set<uint64_t> pending;  // submitted and not yet waited for
     uint64_t next_ticket = 0, next_reduce_seq = 0, reduce_turn = 0;
     bool stop = false;
+    bool hooked = false;  // rt_pipeline_create_hooked: the caller's render / reduce steps instead of rt_render / rt_reduce_accum
+    rt_pipeline_hooks hooks{};
     uint32_t separate = 0;  // slots whose stream was seen to run beside those of all slots before it (slot 0 counts)
     // pacing (see the top of the file)
     double pace = 0.8;
@@ -99,7 +101,8 @@ void worker_main(rt_pipeline* p, size_t s) {
         }
         Done d;
         const auto t_start = std::chrono::steady_clock::now();
-        d.rc = rt_render(slot.ctx, j.width, j.height, j.spp_first, j.spp_count, j.depth, j.seed, j.flags, j.rgb_sum, &d.stats);
+        if (p->hooked) d.rc = p->hooks.render(p->hooks.user, slot.ctx, (uint32_t)s, j.ticket);
+        else d.rc = rt_render(slot.ctx, j.width, j.height, j.spp_first, j.spp_count, j.depth, j.seed, j.flags, j.rgb_sum, &d.stats);
         if (d.rc != RT_OK) d.error = rth::get_error();
         const double took = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         std::unique_lock<std::mutex> lk(p->m);
@@ -108,7 +111,8 @@ void worker_main(rt_pipeline* p, size_t s) {
             p->cv.wait(lk, [&] { return p->reduce_turn == j.reduce_seq; });
             lk.unlock();
             if (d.rc == RT_OK) {  // a frame that failed here leaves the other ranks waiting in theirs: as with rt_render + rt_reduce_accum by hand
-                d.rc = rt_reduce_accum(slot.comm, j.rgb_sum, j.width, j.height, j.reduce_root);
+                if (p->hooked) d.rc = p->hooks.reduce(p->hooks.user, slot.ctx, (uint32_t)s, j.ticket);
+                else d.rc = rt_reduce_accum(slot.comm, j.rgb_sum, j.width, j.height, j.reduce_root);
                 if (d.rc != RT_OK) d.error = rth::get_error();
             }
             lk.lock();
@@ -216,24 +220,22 @@ bool idle(rt_pipeline* p) {  // caller holds p->m
 
 extern "C" {
 
-int rt_pipeline_create(int device, uint32_t frames_in_flight, rt_pipeline** out) try {
+static int create_pipeline(const char* who, int device, uint32_t frames_in_flight, const rt_pipeline_hooks* hooks, rt_pipeline** out) {
     if (!out || frames_in_flight < 1 || frames_in_flight > RT_PIPELINE_MAX_FRAMES) {
-        rth::set_error("rt_pipeline_create: frames_in_flight must be 1..%d", RT_PIPELINE_MAX_FRAMES);
+        rth::set_error("%s: frames_in_flight must be 1..%d", who, RT_PIPELINE_MAX_FRAMES);
         return RT_ERR_INVALID;
     }
     rt_pipeline* p = new rt_pipeline;
     p->device = device;
+    if (hooks) p->hooked = true, p->hooks = *hooks;
     if (const char* e = getenv("RT_PIPELINE_PACE")) p->pace = atof(e);
     p->slots.resize(frames_in_flight);
-    for (Slot& s : p->slots) {
-        int rc = rt_create(device, &s.ctx);
-        if (rc != RT_OK) {
-            shut_down(p);
-            delete p;
-            return rc;
-        }
+    int rc = RT_OK;
+    if (device >= 0) {  // (a hooked pipeline may run without a device: its frames are then the caller's own host work)
+        for (Slot& s : p->slots)
+            if ((rc = rt_create(device, &s.ctx)) != RT_OK) break;
+        if (rc == RT_OK) rc = separate_queues(p);
     }
-    int rc = separate_queues(p);
     if (rc != RT_OK) {
         shut_down(p);
         delete p;
@@ -242,8 +244,53 @@ int rt_pipeline_create(int device, uint32_t frames_in_flight, rt_pipeline** out)
     for (size_t s = 0; s < p->slots.size(); ++s) p->slots[s].worker = std::thread(worker_main, p, s);
     *out = p;
     return RT_OK;
+}
+
+int rt_pipeline_create(int device, uint32_t frames_in_flight, rt_pipeline** out) try {
+    if (device < 0) {
+        rth::set_error("rt_pipeline_create: device %d", device);
+        return RT_ERR_INVALID;
+    }
+    return create_pipeline("rt_pipeline_create", device, frames_in_flight, nullptr, out);
 } catch (...) {
     return rth::on_exception("rt_pipeline_create");
+}
+
+int rt_pipeline_create_hooked(int device, uint32_t frames_in_flight, const rt_pipeline_hooks* hooks, rt_pipeline** out) try {
+    if (!hooks || !hooks->render) {
+        rth::set_error("rt_pipeline_create_hooked: a render hook is needed");
+        return RT_ERR_INVALID;
+    }
+    return create_pipeline("rt_pipeline_create_hooked", device, frames_in_flight, hooks, out);
+} catch (...) {
+    return rth::on_exception("rt_pipeline_create_hooked");
+}
+
+int rt_pipeline_submit_hooked(rt_pipeline* p, int reduce, uint64_t* ticket) try {
+    if (!p || !ticket || !p->hooked) {
+        rth::set_error("rt_pipeline_submit_hooked: not a pipeline of rt_pipeline_create_hooked");
+        return RT_ERR_INVALID;
+    }
+    if (reduce && !p->hooks.reduce) {
+        rth::set_error("rt_pipeline_submit_hooked: a reduce was asked for, but the pipeline has no reduce hook");
+        return RT_ERR_STATE;
+    }
+    Job j;
+    j.reduce_root = reduce ? 0 : RT_PIPELINE_NO_REDUCE;
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        j.ticket = p->next_ticket;
+        if (reduce) j.reduce_seq = p->next_reduce_seq;
+        p->slots[j.ticket % p->slots.size()].jobs.push_back(j);
+        p->pending.insert(j.ticket);
+        ++p->next_ticket;
+        if (reduce) ++p->next_reduce_seq;
+    }
+    p->cv.notify_all();
+    *ticket = j.ticket;
+    return RT_OK;
+} catch (...) {
+    return rth::on_exception("rt_pipeline_submit_hooked");
 }
 
 void rt_pipeline_destroy(rt_pipeline* p) {
@@ -268,6 +315,10 @@ int rt_pipeline_upload_scene(rt_pipeline* p, const rt_scene_flat* scene) try {
     if (!p || !scene) {
         rth::set_error("rt_pipeline_upload_scene: null argument");
         return RT_ERR_INVALID;
+    }
+    if (p->device < 0) {
+        rth::set_error("rt_pipeline_upload_scene: the pipeline has no device");
+        return RT_ERR_STATE;
     }
     {
         std::lock_guard<std::mutex> lk(p->m);
@@ -304,6 +355,10 @@ int rt_pipeline_comm_create(rt_pipeline* p, const uint8_t* ids, int world_size, 
         rth::set_error("rt_pipeline_comm_create: null argument");
         return RT_ERR_INVALID;
     }
+    if (p->device < 0) {
+        rth::set_error("rt_pipeline_comm_create: the pipeline has no device");
+        return RT_ERR_STATE;
+    }
     {
         std::lock_guard<std::mutex> lk(p->m);
         if (!idle(p)) {
@@ -331,6 +386,10 @@ int rt_pipeline_submit(rt_pipeline* p, uint32_t width, uint32_t height, uint32_t
     if (!p || !rgb_sum || !ticket) {
         rth::set_error("rt_pipeline_submit: null argument");
         return RT_ERR_INVALID;
+    }
+    if (p->hooked) {
+        rth::set_error("rt_pipeline_submit: the pipeline renders through hooks (rt_pipeline_submit_hooked)");
+        return RT_ERR_STATE;
     }
     if (reduce_root != RT_PIPELINE_NO_REDUCE && !p->slots[0].comm) {
         rth::set_error("rt_pipeline_submit: a reduce was asked for, but rt_pipeline_comm_create has not been called");

@@ -177,3 +177,40 @@ def test_reduce_world_size_2_frames_pair_up(tmp_path):
     for k in range(len(got)):
         parts = [orc.render(64, 36, c, 8, 5 + k, f)[0] for f, c in (sample_shard(8, 2, r) for r in range(2))]
         assert np.array_equal(got[k].view(np.uint32), (parts[0] + parts[1]).view(np.uint32)), k
+
+
+def test_hooked_pipeline_gives_each_hook_its_slots_context():
+    """rt_pipeline_create_hooked with a device: the render hook gets the slot's context and may run any calls on it --
+    here Engine::ray_colour in batch form (rt_ray_colour) for frames of caller rays, two at a time."""
+    desc = scenes.path_scene(levels=4, glass_levels=2)
+    scene = rt.Scene(desc)
+    cam = scene.flat.camera
+    org, dirs = scenes.pixel_center_rays(cam, 48, 27)
+    results, errors = {}, []
+
+    def render(ctx_addr, slot, ticket):
+        try:
+            ctx = rt.Context(_borrowed=(ctx_addr, pipe))
+            results[ticket] = (slot, ctx.ray_colour(org, dirs, 2, 8, seed=ticket)[0])
+            return 0
+        except Exception as e:  # reported through the status; the text is kept for the assertion below
+            errors.append(repr(e))
+            return -1
+
+    pipe = rt.FramePipeline(0, 2, render=render)
+    pipe.upload(scene)
+    for t in [pipe.submit_hooked() for _ in range(5)]:
+        pipe.wait(t)
+    assert not errors, errors
+    with pytest.raises(rt.RtError, match="no reduce hook"):
+        pipe.submit_hooked(reduce=True)
+    ctx = pipe.context(0)
+    for ticket, (slot, img) in results.items():
+        assert slot == ticket % 2
+        ref, _ = ctx.ray_colour(org, dirs, 2, 8, seed=ticket)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    orc = ob.OracleScene(desc)
+    ref0 = orc.ray_colour(org, dirs, 2, 8, seed=0)
+    ref0 = ref0[0] if isinstance(ref0, tuple) else ref0
+    assert np.array_equal(results[0][1].view(np.uint32), np.asarray(ref0, np.float32).reshape(-1, 3).view(np.uint32))
+    pipe.close()
