@@ -424,10 +424,13 @@ def main():
                          "traffic_detail": traffic_detail,
                          "stream_copy_GBs": round(stream_copy, 1),
                          "kernel": result["kernel"], "kernel_ms": round(result["kernel_ms"], 4),
+                         **({"frac_with_frames_in_flight": round(traffic / (result["kernel_ms_with_frames_in_flight"]["kernel_ms_extend"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                            if traffic is not None and (result.get("kernel_ms_with_frames_in_flight") or {}).get("kernel_ms_extend") else {}),
                          **({"kernel_ms_note": "launch duration with ONE frame on the GPU (3 frames rendered one at a time right after the "
                                                "timed region; bench.py --frames-in-flight 1 times exactly those, and the committed rocprofv3 "
                                                "summary is of that command): with frames in flight the launches of different frames share "
-                                               "the CUs, and an event pair on one stream spans both (detail.kernel_ms_with_frames_in_flight)"}
+                                               "the CUs, and an event pair on one stream spans both (detail.kernel_ms_with_frames_in_flight; frac_with_frames_in_flight "
+                                               "divides the same traffic by that stretched duration)"}
                             if result.get("frames_in_flight", 1) > 1 else {}),
                          "alg_bytes_per_launch": int(result["alg_bytes"]),
                          "alg_bytes_note": "48 + 64 N_int + 40 N_tri per ray with N_int / N_tri counted on the TIMED kernel's own fetches "

@@ -166,7 +166,10 @@ int separate_queues(rt_pipeline* p) {
     const unsigned long long ticks = (unsigned long long)khz * 2ull;  // 2 ms
     hipEvent_t ea = nullptr, eb = nullptr;
     RT_HIP(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
-    RT_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    if (hipError_t e = hipEventCreateWithFlags(&eb, hipEventDisableTiming); e != hipSuccess) {
+        (void)hipEventDestroy(ea);
+        RT_HIP(e);
+    }
     std::vector<hipStream_t> rejects;
     int rc = RT_OK;
     for (size_t k = 1; k < p->slots.size() && rc == RT_OK; ++k) {
