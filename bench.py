@@ -53,8 +53,8 @@ GATHER_L1_GBS = 214.0 * 64
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)  # frames in flight: the first and last frames of a run have the GPU to themselves
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["render", "trace", "config5"], default="render")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--instanced", action="store_true", help="config5: ten instances of ONE mesh/BVH instead of ten meshes")
