@@ -28,7 +28,9 @@ def test_frames_in_flight_are_the_oracles_frames(n_frames_in_flight):
     desc = scenes.path_scene(levels=5, glass_levels=3, medium=True, sigma_s=0.5)
     pipe = rt.FramePipeline(0, n_frames_in_flight)
     assert pipe.frames_in_flight == n_frames_in_flight
-    assert pipe.separate_queues == n_frames_in_flight  # up to the GPU's hardware queues (4 here), every slot gets its own
+    # up to the GPU's hardware queues (4 by default) every slot gets its own; the third could share one in a process
+    # that keeps other streams busy, the second never has to
+    assert min(2, n_frames_in_flight) <= pipe.separate_queues <= n_frames_in_flight
     pipe.upload(rt.Scene(desc))
     orc = ob.OracleScene(desc)
     frames = _frames()
