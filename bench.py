@@ -115,7 +115,8 @@ def main():
             spp_first, spp_count = sample_shard(args.spp, world, rank)
         else:                          # every rank its own args.spp samples
             spp_first, spp_count = rank * args.spp, args.spp
-        n_flight = args.frames_in_flight or (2 if args.spp // world >= 32 else 4)  # the same on every rank
+        # the same on every rank (the ranks' shares may differ by one sample): communicators are created slot by slot
+        n_flight = args.frames_in_flight or (2 if (args.spp // world if args.scaling == "strong" else args.spp) >= 32 else 4)
         if args.torch_reduce:
             n_flight = 1
     if n_flight > 1:  # one context per frame in flight; slot 0's context also serves the untimed passes
