@@ -91,6 +91,7 @@ RT_DEV float4 ld16(const void* base, uint32_t byte_off) {
 //                                          the ray in every later call -- `i` below -- so that a policy whose
 //                                          rays sit behind a queue looks its slot up once
 //   hit(i, t, n, meta, prim)               closest-hit rays: a hit closer than any before it on ray i
+//   escaped(i, o, d)                       closest-hit ray i (world-space o, d) finished without a hit; before emit_closest / next
 //   emit_closest(i, got, vis)              closest-hit ray i is finished
 //   emit_any(i, occluded, vis)             any-hit ray i is finished
 //   TRACE_PATH only (CONTINUES = true: next() may continue the lane with another ray, so finished lanes are
@@ -185,6 +186,9 @@ RT_DEV void trace_loop(const DScene& sc, IO& io, uint32_t n, uint32_t* work_coun
 
     // a ray is finished: hand it to the IO policy now, or (TRACE_PATH) park the lane for phase D
     auto finish = [&](bool occluded) {
+        if constexpr (MODE != TRACE_ANY) {  // a closest-hit ray that met nothing: the policy gets the ray itself (rt_render marks
+            if (!(PATH && lane_any) && !got) io.escaped(ray, wo, wd);  // the ones no light lies on, see k_classify)
+        }
         if constexpr (PARK) {
             cur = REF_DONE;
             done_occluded = occluded;

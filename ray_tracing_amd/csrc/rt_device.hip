@@ -97,6 +97,7 @@ struct TraceIO {  // caller-provided SoA ray batch and hit arrays (rt_rays / rt_
         if (out.nz) out.nz[i] = n.z;
         if (out.front_face) out.front_face[i] = (uint8_t)(meta >> 31);
     }
+    RT_DEV void escaped(uint32_t, const V3&, const V3&) const {}
     RT_DEV void emit_closest(uint32_t i, bool got, const Visits& vis) const {
         if (!got) {
             out.t[i] = __builtin_inff();

@@ -337,12 +337,12 @@ int rt_pipeline_upload_scene(rt_pipeline* p, const rt_scene_flat* scene) try {
         reusable += s.ctx->path_state.bytes;
     }
     // rt_render sizes a context's path state from the free HBM it finds (40 %): the first context of several would
-    // take most of it.  Share 80 % of what is free now among the contexts instead (192 B per path slot, as there).
+    // take most of it.  Share 80 % of what is free now among the contexts instead (196 B per path slot, as there).
     RT_HIP(hipSetDevice(p->device));
     size_t free_b = 0, total_b = 0;
     RT_HIP(hipMemGetInfo(&free_b, &total_b));
     const double share = (double)(free_b + reusable) * 0.8 / (double)p->slots.size();
-    uint64_t max_paths = (uint64_t)(share / 192.0);
+    uint64_t max_paths = (uint64_t)(share / 196.0);
     if (max_paths < ((uint64_t)1 << 20)) max_paths = (uint64_t)1 << 20;
     for (Slot& s : p->slots) {
         int rc = rt_set_max_paths_in_flight(s.ctx, max_paths);

@@ -47,6 +47,7 @@ constexpr uint32_t QF_ALIVE = 1u, QF_SHADOW = 2u, QF_SKIPPED = 4u;  // QF_SKIPPE
 constexpr uint32_t NSEG = WORK_MAX_SEG;
 static_assert(NSEG == 64, "k_publish is one wave, one lane per segment");
 constexpr uint32_t ACC_STRIDE = 16;  // u64 between accumulators: one 128-byte line each
+constexpr uint32_t LIST_STRIDE = 32; // u32 between the list counters: one 128-byte line each
 // A bounce of n paths uses ns = 2^k <= NSEG segments of stride NSEG / ns * seg_cap (segments_for() on the host: what
 // a launch of n rays wants as work segments, 64 from 8 Mi rays up, one below 256 Ki) -- a small launch over 128 nearly
 // empty segments spends its time on their counters -- and since paths only die, ns only shrinks from bounce to bounce: a
@@ -84,6 +85,9 @@ struct PathArrays {      // the arrays one bounce works on (all indexed by POSIT
     uint32_t* work;      // WORK_BUF_U32 (device_trace.h), zeroed by k_publish of every bounce: closest-hit launches (and the
                          // tail kernel) use the first NSEG counters, shadow launches the second NSEG, a mixed launch all of
                          // them (its 2 NSEG segments in order) -- each counter serves one launch per bounce
+    const uint32_t* list;  // k_shade: the positions (inside their segment) of the paths that need shading, per segment, dense from the
+                           // segment's first position (k_classify); null = every position below the segment's count
+    uint32_t* list_cnt;    // [NSEG * LIST_STRIDE] entries of `list` per segment; zeroed by k_publish
     unsigned long long* tail;   // k_tail totals (see k_tail)
     unsigned long long* visit; // [0] n_int extend, [1] n_tri extend, [2] n_int shadow, [3] n_tri shadow
 };
@@ -187,6 +191,30 @@ RT_DEV void add_visits(unsigned long long* dst, unsigned long long a, unsigned l
     }
 }
 
+// Light record l for a wave-uniform l: read through the constant address space (scalar loads into SGPRs, see
+// rtd::CObject) instead of one vector round trip per field.
+RT_DEV rt_light load_light_uniform(const rt_light* lights, uint32_t l) {
+    static_assert(sizeof(rt_light) == 44, "rt_light is copied as 11 dwords");
+    const __attribute__((address_space(4))) uint32_t* p = (const __attribute__((address_space(4))) uint32_t*)(lights + l);
+    uint32_t w[11];
+    for (int i = 0; i < 11; ++i) w[i] = p[i];
+    rt_light out;
+    __builtin_memcpy(&out, w, sizeof out);
+    return out;
+}
+
+// A closest-hit ray of a path that met nothing (:155-173): hit_light over the whole ray decides whether the path has
+// anything left to do -- add the light's radiance -- or is simply over; the trace kernel has the ray in registers, so it
+// says so in the second word of the miss record (k_classify reads that word instead of the ray).
+RT_DEV void mark_escaped(const DScene& sc, const PathArrays& pa, uint32_t k, const V3& o, const V3& d) {
+    uint32_t lit = 0u;
+    for (uint32_t l = 0; l < sc.n_lights; ++l) {
+        float t;
+        if (light_hit(load_light_uniform(sc.lights, l), o, d, T_MIN, __builtin_inff(), &t)) lit = 1u;
+    }
+    pa.hit_b[k] = make_uint2(RT_MISS, lit);
+}
+
 // FIRST: 1 = always the first bounce of an implicit frame, 0 = never, -1 = decided at run time (`first`).  The lean kernel has
 // one instantiation for each: with both ray sources in one kernel the loop loses registers to scalar spills.
 template <int FIRST = -1>
@@ -223,8 +251,11 @@ struct ExtendIOT {  // ray i = the path at position i; hits go to the position's
         ((float*)&pa.hit_a[i])[0] = t;
         pa.hit_b[i] = make_uint2(meta, tri);
     }
-    RT_DEV void emit_closest(uint32_t i, bool got, const Visits& vis) {
-        if (!got) pa.hit_b[i] = make_uint2(RT_MISS, RT_MISS);
+    RT_DEV void escaped(uint32_t i, const V3& o, const V3& d) const {
+        if (FIRST > 0) pa.hit_b[i] = make_uint2(RT_MISS, 1u);  // the first shade looks at every path (no list): nothing to find out
+        else mark_escaped(sc, pa, i, o, d);
+    }
+    RT_DEV void emit_closest(uint32_t, bool, const Visits& vis) {
         n_int += vis.n_int;
         n_tri += vis.n_tri;
     }
@@ -300,6 +331,7 @@ struct ShadowIO {  // ray i = shadow record i; an unoccluded ray adds its pendin
     }
     static constexpr bool DEFER_NORMAL = false;
     RT_DEV void hit(uint32_t, float, V3, uint32_t, uint32_t) const {}
+    RT_DEV void escaped(uint32_t, const V3&, const V3&) const {}
     RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
     RT_DEV void emit_any(uint32_t i, bool occluded, const Visits& vis) {
         if (!occluded) add_pending_nee(pa, i, __float_as_uint(pa.sh_o[i].w));
@@ -338,18 +370,6 @@ RT_DEV float mis_weight(float pa, float pb) {  // path_integrator.rs:30-39, powe
     float b = pb * pb;
     if (a + b == 0.0f) return 0.0f;
     return a / (a + b);
-}
-
-// Light record l for a wave-uniform l: read through the constant address space (scalar loads into SGPRs, see
-// rtd::CObject) instead of one vector round trip per field.
-RT_DEV rt_light load_light_uniform(const rt_light* lights, uint32_t l) {
-    static_assert(sizeof(rt_light) == 44, "rt_light is copied as 11 dwords");
-    const __attribute__((address_space(4))) uint32_t* p = (const __attribute__((address_space(4))) uint32_t*)(lights + l);
-    uint32_t w[11];
-    for (int i = 0; i < 11; ++i) w[i] = p[i];
-    rt_light out;
-    __builtin_memcpy(&out, w, sizeof out);
-    return out;
 }
 
 // What an iteration leaves behind besides radiance: the state of the path's next ray (QF_ALIVE) and its shadow ray
@@ -528,8 +548,62 @@ RT_DEV uint32_t shade_path(const DScene& sc, const PathArrays& pa, const RenderP
     return flags;
 }
 
+// Which paths of a bounce have anything to shade.  From the second bounce on most rays leave the scene (four in five
+// after the first diffuse bounce of the bench frame) and nineteen in twenty of those pass every light: shade_path reads
+// 76 B of state for each to find that it has nothing to do, and the paths that did hit something are scattered thinly
+// over the waves -- a wave pays the whole shading sequence for a dozen busy lanes (second k_shade of the bench frame:
+// 4.3 ms, of which 2.4 for reading the escaped paths and 1.9 for 21 M hits that cost 0.8 when they are dense).  This
+// kernel lists the positions that need shade_path -- a hit, or a light on the escaped ray (hit_light over the whole ray,
+// :107-121; `any` light is all that matters here: the trace kernels test it while they have the ray, mark_escaped, and
+// say so in the miss record, so 8 B per path are all this kernel reads) -- per segment, in position order up to the order the blocks'
+// reservations arrive in; k_shade then runs on the list.  A path that is not listed is one for which shade_path
+// returns 0 without touching anything.
+constexpr uint32_t CLASSIFY_TILE = SHADE_BLOCK * 4;  // four consecutive positions per thread: 32 B of miss / hit records
+__global__ __launch_bounds__(SHADE_BLOCK) void k_classify(PathArrays pa, uint32_t* list) {
+    __shared__ uint32_t wave_cnt[SHADE_BLOCK / 64];
+    __shared__ uint32_t base;
+    const uint32_t seg = blockIdx.x % pa.ns, first = (blockIdx.x / pa.ns) * CLASSIFY_TILE;
+    const uint32_t n = pa.cnt[CNT_ALIVE + seg];
+    if (first >= n) return;
+    const uint32_t seg0 = seg * pa.seg_stride, p0 = first + threadIdx.x * 4u;
+    uint32_t bits = 0u;  // bit j: position p0 + j needs shading -- a hit, or an escaped ray with a light on it (mark_escaped)
+    if (p0 + 3u < n) {   // (segments start at multiples of the shade block: the four records are 32-byte aligned)
+        const uint4* h = reinterpret_cast<const uint4*>(pa.hit_b + seg0 + p0);
+        const uint4 a = h[0], b = h[1];
+        bits = ((a.x != RT_MISS || a.y != 0u) ? 1u : 0u) | ((a.z != RT_MISS || a.w != 0u) ? 2u : 0u) |
+               ((b.x != RT_MISS || b.y != 0u) ? 4u : 0u) | ((b.z != RT_MISS || b.w != 0u) ? 8u : 0u);
+    } else {
+        for (uint32_t q = 0; q < 4u && p0 + q < n; ++q) {
+            const uint2 hb = pa.hit_b[seg0 + p0 + q];
+            if (hb.x != RT_MISS || hb.y != 0u) bits |= 1u << q;
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint32_t before = 0u, total = 0u;  // listed positions in the lanes below this one / in the wave
+    for (uint32_t q = 0; q < 4u; ++q) {
+        const unsigned long long m = __ballot((bits >> q) & 1u);
+        before += (uint32_t)__popcll(m & below);
+        total += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) wave_cnt[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < SHADE_BLOCK / 64; ++w) t += wave_cnt[w];
+        base = t ? atomicAdd(&pa.list_cnt[seg * LIST_STRIDE], t) : 0u;
+    }
+    __syncthreads();
+    if (bits) {
+        uint32_t pos = seg0 + base + before;
+        for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[w];
+        for (uint32_t q = 0; q < 4u; ++q)
+            if ((bits >> q) & 1u) list[pos++] = p0 + q;
+    }
+}
+
 // Block b works on segment b % ns (consecutive blocks on different segments: see NSEG above), on the 256 positions
-// from (b / ns) * 256 of that segment.  After shading, the block's survivors and shadow rays are counted (ballots),
+// from (b / ns) * 256 of that segment (of the segment's list, when the bounce has one).  After shading, the block's survivors and shadow rays are counted (ballots),
 // the block reserves room for both in its segment of the next region / of the shadow records with one atomic, and
 // every lane writes its records to its place: block offset + waves before + rank inside the wave's ballot.  Inside a
 // block the order of the paths is kept, between blocks it is the order the reservations arrive in -- close to the
@@ -538,13 +612,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa,
     __shared__ uint32_t wave_cnt[3][SHADE_BLOCK / 64];
     __shared__ uint32_t base[2];
     const uint32_t seg = blockIdx.x % pa.ns, first = (blockIdx.x / pa.ns) * SHADE_BLOCK;
-    const uint32_t n = pa.cnt[CNT_ALIVE + seg];
+    const uint32_t n = pa.list ? pa.list_cnt[seg * LIST_STRIDE] : pa.cnt[CNT_ALIVE + seg];
     if (first >= n) return;  // the grid is sized from an upper bound of the fullest segment (uniform per block)
     const uint32_t local = first + threadIdx.x, seg0 = seg * pa.seg_stride;
     const uint32_t oseg = seg / (pa.ns / pa.ns_out), oseg0 = oseg * pa.out_stride;  // where this segment's survivors go
     uint32_t flags = 0;
     ShadeOut out;
-    if (local < n) flags = shade_path(sc, pa, rp, seg0 + local, rp.bounce, out);
+    if (local < n) flags = shade_path(sc, pa, rp, seg0 + (pa.list ? pa.list[seg0 + local] : local), rp.bounce, out);
     const unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
     const unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
     const unsigned long long skipped = __ballot((flags & QF_SKIPPED) != 0);
@@ -624,6 +698,7 @@ __global__ __launch_bounds__(64) void k_publish(PathArrays pa, uint32_t* cnt_out
         ma = max(ma, (uint32_t)__shfl_down(ma, off));
     }
     for (uint32_t i = s; i < WORK_BUF_U32; i += 64u) pa.work[i] = 0u;
+    pa.list_cnt[s * LIST_STRIDE] = 0u;
     if (s == 0) {
         const uint32_t sk = *pa.acc_skipped;
         *pa.acc_skipped = 0u;
@@ -678,6 +753,7 @@ struct TailIO {
         pa.hit_a[i] = make_float4(t, n.x, n.y, n.z);
         pa.hit_b[i] = make_uint2(meta, prim);
     }
+    RT_DEV void escaped(uint32_t, const V3&, const V3&) const {}  // (next() writes the miss record: the lane shades it itself)
     RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
     RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
     RT_DEV bool next_bounce(uint32_t i, V3* o, V3* d, bool* any) {
@@ -764,6 +840,7 @@ struct MixedIO {
     PathArrays pa;
     uint32_t n_shadow_items;  // NSEG * seg_cap: items below it are shadow records, item i at or above it is position i - n_shadow_items
     unsigned long long n_int, n_tri, n_int_sh, n_tri_sh;
+    const DScene* sc;
     static constexpr bool CONTINUES = false;  // a finished ray is finished: the lane takes a new one
     RT_DEV bool first_is_any(uint32_t i) const { return i < n_shadow_items; }
     RT_DEV uint32_t load(uint32_t i, V3* o, V3* d) const {  // the tag is the item
@@ -792,6 +869,7 @@ struct MixedIO {
         pa.hit_a[k] = make_float4(t, n.x, n.y, n.z);
         pa.hit_b[k] = make_uint2(meta, prim);
     }
+    RT_DEV void escaped(uint32_t i, const V3& o, const V3& d) const { mark_escaped(*sc, pa, i - n_shadow_items, o, d); }
     RT_DEV void emit_closest(uint32_t, bool, const Visits&) {}
     RT_DEV void emit_any(uint32_t, bool, const Visits&) {}
     RT_DEV bool next(uint32_t i, bool was_any, bool got, bool occluded, const Visits& vis, V3*, V3*, bool*) {
@@ -802,7 +880,6 @@ struct MixedIO {
         } else {
             n_int += vis.n_int;
             n_tri += vis.n_tri;
-            if (!got) pa.hit_b[i - n_shadow_items] = make_uint2(RT_MISS, RT_MISS);
         }
         return false;
     }
@@ -814,7 +891,7 @@ __global__ RT_TRACE_ATTR void k_mixed(DScene sc, PathArrays pa, TuneBase base, u
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n = pa.cnt[CNT_TOT_SHADOW] + pa.cnt[CNT_TOT_ALIVE];  // shadow rays of this bounce, then the rays of the next
     const TraceTune tune = render_tune(base, n, 2u * pa.ns, pa.seg_stride);
-    MixedIO io{pa, pa.n_positions, 0ull, 0ull, 0ull, 0ull};
+    MixedIO io{pa, pa.n_positions, 0ull, 0ull, 0ull, 0ull, &sc};
     trace_loop<TRACE_PATH, COUNT, RT_STACK_LDS, RT_BLOCK>(sc, io, n, pa.work, tune, T_MIN, __builtin_inff(),
                                                           lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_MIXED, 0u, pa.cnt + CNT_LIVE_MIXED);
     if (COUNT) {  // accounted with the tail kernel's share: rays traced outside k_extend / k_shadow
@@ -828,7 +905,7 @@ __global__ RT_TRACE_ATTR_LEAN void k_mixed_lean(DScene sc, PathArrays pa, TuneBa
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t n = pa.cnt[CNT_TOT_SHADOW] + pa.cnt[CNT_TOT_ALIVE];
     const TraceTune tune = render_tune(base, n, 2u * pa.ns, pa.seg_stride);
-    MixedIO io{pa, pa.n_positions, 0ull, 0ull, 0ull, 0ull};
+    MixedIO io{pa, pa.n_positions, 0ull, 0ull, 0ull, 0ull, &sc};
     trace_loop<TRACE_PATH, false, RT_STACK_LEAN, RT_BLOCK, RT_LEAN_FEAT, RT_LEAN_OVERFLOW>(
         sc, io, n, pa.work, tune, T_MIN, __builtin_inff(), lds_stack + threadIdx.x, overflow + gtid, overflow_stride, pa.cnt + CNT_MIXED, 0u, pa.cnt + CNT_LIVE_MIXED);
 }
@@ -944,13 +1021,13 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     // ---- batch size: samples in flight at once.  Every wavefront iteration ends in a tail of
     // half-empty waves and a host round trip, so the batch is made as large as memory allows
     // (measured at 1080p/32 spp: 8 Mi paths 145 ms, 64 Mi paths 71 ms): by default up to 40 % of
-    // the free HBM, 192 B per path slot (two regions of 52 B, hit 24 B, shadow record 48 B, radiance 16 B).
+    // the free HBM, 196 B per path slot (two regions of 52 B, hit 24 B, shadow record 48 B, radiance 16 B, list entry 4 B).
     uint64_t max_paths = ctx->max_paths_in_flight;
     if (max_paths == 0) {
         size_t free_b = 0, total_b = 0;
         RT_HIP(hipMemGetInfo(&free_b, &total_b));
         free_b += ctx->path_state.bytes;  // our own previous allocation is reusable
-        max_paths = (uint64_t)((double)free_b * 0.4 / 192.0);
+        max_paths = (uint64_t)((double)free_b * 0.4 / 196.0);
         if (max_paths < ((uint64_t)1 << 20)) max_paths = (uint64_t)1 << 20;
     }
     uint32_t s_batch = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
@@ -977,8 +1054,10 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     const size_t o_hit_a = carve(Ppos * 16), o_hit_b = carve(Ppos * 8), o_sh_o = carve(Ppos * 16), o_sh_d = carve(Ppos * 16),
                  o_sh_c = carve(Ppos * 16), o_rad = carve(P * 16);
     // small state, zeroed together at the start of every batch: accumulators, skipped total, work counters
-    const size_t o_acc = carve((size_t)NSEG * ACC_STRIDE * 8), o_skip = carve(256), o_work = carve(rtd::WORK_BUF_U32 * 4);
+    const size_t o_acc = carve((size_t)NSEG * ACC_STRIDE * 8), o_skip = carve(256), o_work = carve(rtd::WORK_BUF_U32 * 4),
+                 o_lcnt = carve((size_t)NSEG * LIST_STRIDE * 4);
     const size_t zero_bytes = off - o_acc;
+    const size_t o_list = carve(Ppos * 4);
     const size_t o_cnt = carve(2 * CNT_U32 * 4), o_vis = carve(256), o_tail = carve(256);
     int rc = ctx->path_state.ensure(off);
     if (rc != RT_OK) return rc;
@@ -1020,6 +1099,8 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         q.ns_out = ns_of[k + 1];
         q.out_stride = seg_cap * (NSEG / q.ns_out);
         q.work = (uint32_t*)(base + o_work);
+        q.list = nullptr;
+        q.list_cnt = (uint32_t*)(base + o_lcnt);
         q.visit = (unsigned long long*)(base + o_vis);
         q.tail = (unsigned long long*)(base + o_tail);
         return q;
@@ -1057,6 +1138,10 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
     static const uint32_t tail_paths = [] {  // RT_TAIL_PATHS overrides the switch-over point (experiments)
         const char* e = getenv("RT_TAIL_PATHS");
         return e ? (uint32_t)strtoul(e, nullptr, 10) : 131072u;  // profiles/r03/tuning.md section 4
+    }();
+    static const uint32_t list_paths = [] {  // RT_LIST_PATHS: bounces after the first with at least this many paths are shaded from a list (0: never)
+        const char* e = getenv("RT_LIST_PATHS");
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 18);  // profiles/r03/tuning.md section 11
     }();
     static const uint32_t async_below = [] {  // RT_ASYNC_BELOW: bounces with at most this many paths are enqueued
         const char* e = getenv("RT_ASYNC_BELOW");  // without waiting for their exact counts (0: always wait)
@@ -1261,7 +1346,13 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
             // shade + compaction: NSEG interleaved segments, grid sized from the fullest one
             const uint32_t seg_blocks = (seg_ub + SHADE_BLOCK - 1) / SHADE_BLOCK;
             if ((rc = t_begin(2)) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_shade, dim3(seg_blocks * pr.ns), dim3(SHADE_BLOCK), 0, stream, ctx->scene, pr, rp);
+            PathArrays ps = pr;
+            if (k > 0 && list_paths > 0 && n_ub >= list_paths) {  // (the first bounce's paths nearly all hit something)
+                uint32_t* const list = (uint32_t*)(base + o_list);
+                hipLaunchKernelGGL(k_classify, dim3((seg_ub + CLASSIFY_TILE - 1) / CLASSIFY_TILE * pr.ns), dim3(SHADE_BLOCK), 0, stream, pr, list);
+                ps.list = list;
+            }
+            hipLaunchKernelGGL(k_shade, dim3(seg_blocks * pr.ns), dim3(SHADE_BLOCK), 0, stream, ctx->scene, ps, rp);
             if ((rc = t_end(2)) != RT_OK) return rc;
             if (ns_of.size() < k + 3) ns_of.resize(k + 3, ns_of[k + 1]);
             ns_of[k + 2] = ns_of[k + 1];  // placeholder until bounce k + 1 decides it (view(k + 1) only uses it for its own shade)

@@ -182,3 +182,47 @@ def test_device_output_buffer(ctx):
     ctx.render(64, 36, 3, 8, 1, out=out.data_ptr())
     ref, _ = ob.OracleScene(desc).render(64, 36, 3, 8, 1)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+_LISTED = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import oracle_binding as ob
+import ray_tracing_amd as rt
+from ray_tracing_amd import scenes
+ctx = rt.Context(0)
+stl = os.path.join(sys.argv[1], "tests", "golden", "baby_yoda.stl")
+cases = [(scenes.path_scene(levels=5, glass_levels=3), 96, 54, 4, 16, 3),
+         (scenes.path_scene(levels=4, glass_levels=3, medium=True, sigma_s=2.0), 80, 45, 4, 16, 11),
+         (scenes.volumetric_sphere(), 80, 45, 6, 16, 5),
+         (scenes.primitives_scene(), 96, 54, 4, 16, 2),
+         (scenes.spotlight_scene(levels=3), 96, 54, 4, 16, 21),
+         (scenes.baby_yoda_scene(stl, sigma_s=0.05, extra_mesh_levels=4), 96, 54, 4, 16, 8),
+         (scenes.path_scene(levels=5, glass_levels=3), 320, 180, 4, 16, 9)]
+for desc, w, h, spp, depth, seed in cases:
+    ctx.upload(rt.Scene(desc))
+    orc = ob.OracleScene(desc)
+    ref, ost = orc.render(w, h, spp, depth, seed)
+    for flags in (0, rt.api.RENDER_NO_TAIL, rt.api.RENDER_COUNT_VISITS | rt.api.RENDER_NO_TAIL):
+        img, st = ctx.render(w, h, spp, depth, seed, flags=flags)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (w, h, seed, flags)
+        assert (st.rays_closest, st.rays_shadow) == (ost.rays_closest, ost.rays_shadow)
+        if flags & rt.api.RENDER_COUNT_VISITS:
+            assert st.nodes_visited + st.nodes_visited_shadow == ost.nodes_visited
+print("listed ok")
+'''
+
+
+def test_shading_from_the_list_at_every_bounce(tmp_path):
+    """k_classify + list-driven k_shade normally serve bounces of 262 144 paths and more (the full-size tests); here
+    RT_LIST_PATHS=1 sends EVERY bounce after the first through them, with and without the tail kernel, on scenes with
+    every material, light and medium kind -- in a process of its own, because the threshold is read once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "listed.py"
+    script.write_text(_LISTED)
+    env = dict(os.environ, RT_LIST_PATHS="1", RT_TAIL_PATHS="64")
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "listed ok" in r.stdout, r.stderr[-3000:]
