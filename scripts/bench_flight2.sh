@@ -1,4 +1,7 @@
 #!/bin/bash
+# bench.py with 2 / 3 / 4 frames in flight, the forced-distributed rehearsal and the 8-spp share: what produced
+# profiles/r03/flight_priorities.txt (p1_* there came from a throw-away build whose slots had streams of different
+# priorities, switched on with RT_PIPELINE_PRIORITIES=1; the library no longer reads that variable)
 set -e
 O=gpurun_out/flight2; mkdir -p $O
 for pr in 0; do
