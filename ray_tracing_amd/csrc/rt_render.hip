@@ -608,53 +608,63 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_classify(PathArrays pa, uint32_
 // every lane writes its records to its place: block offset + waves before + rank inside the wave's ballot.  Inside a
 // block the order of the paths is kept, between blocks it is the order the reservations arrive in -- close to the
 // launch order, so what was coherent stays so, and no bit of the image depends on it.
+// LISTED: the grid is ns x (tiles per segment, capped at RT_SHADE_TILES) and a block takes every (gridDim.x / ns)-th tile of its
+// segment's list.  The grid can only be sized from what the list is drawn from; one block per tile starts a million blocks
+// to find four in five of them beyond the list's end, each holding a wave slot for the microsecond its count takes to
+// arrive.  The dense launches keep one tile per block: the same loop around their tile costs them 13 % (registers live
+// across it, a third barrier).
+template <bool LISTED>
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, PathArrays pa, RenderParams rp) {
     __shared__ uint32_t wave_cnt[3][SHADE_BLOCK / 64];
     __shared__ uint32_t base[2];
-    const uint32_t seg = blockIdx.x % pa.ns, first = (blockIdx.x / pa.ns) * SHADE_BLOCK;
-    const uint32_t n = pa.list ? pa.list_cnt[seg * LIST_STRIDE] : pa.cnt[CNT_ALIVE + seg];
-    if (first >= n) return;  // the grid is sized from an upper bound of the fullest segment (uniform per block)
-    const uint32_t local = first + threadIdx.x, seg0 = seg * pa.seg_stride;
+    const uint32_t seg = blockIdx.x % pa.ns, tile_stride = LISTED ? (gridDim.x / pa.ns) * SHADE_BLOCK : 0xFFFFFF00u;
+    const uint32_t n = LISTED ? pa.list_cnt[seg * LIST_STRIDE] : pa.cnt[CNT_ALIVE + seg];
+    const uint32_t seg0 = seg * pa.seg_stride;
     const uint32_t oseg = seg / (pa.ns / pa.ns_out), oseg0 = oseg * pa.out_stride;  // where this segment's survivors go
-    uint32_t flags = 0;
-    ShadeOut out;
-    if (local < n) flags = shade_path(sc, pa, rp, seg0 + (pa.list ? pa.list[seg0 + local] : local), rp.bounce, out);
-    const unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
-    const unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
-    const unsigned long long skipped = __ballot((flags & QF_SKIPPED) != 0);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        wave_cnt[0][wave] = (uint32_t)__popcll(alive);
-        wave_cnt[1][wave] = (uint32_t)__popcll(shadow);
-        wave_cnt[2][wave] = (uint32_t)__popcll(skipped);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t[3] = {0, 0, 0};
-        for (int w = 0; w < SHADE_BLOCK / 64; ++w)
-            for (int q = 0; q < 3; ++q) t[q] += wave_cnt[q][w];
-        unsigned long long r = 0ull;
-        if (t[0] | t[1]) r = atomicAdd(&pa.acc[oseg * ACC_STRIDE], (unsigned long long)t[0] | ((unsigned long long)t[1] << 32));
-        base[0] = (uint32_t)r;
-        base[1] = (uint32_t)(r >> 32);
-        if (t[2]) atomicAdd(pa.acc_skipped, t[2]);
-    }
-    __syncthreads();
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    if (flags & QF_ALIVE) {
-        uint32_t pos = oseg0 + base[0] + (uint32_t)__popcll(alive & below);
-        for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[0][w];
-        pa.nray_o[pos] = out.o4;
-        pa.nray_d[pos] = out.d4;
-        pa.nbeta[pos] = out.b4;
-        pa.noid[pos] = out.id;
-    }
-    if (flags & QF_SHADOW) {
-        uint32_t pos = oseg0 + base[1] + (uint32_t)__popcll(shadow & below);
-        for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[1][w];
-        pa.sh_o[pos] = make_float4(out.o4.x, out.o4.y, out.o4.z, __uint_as_float(out.id));
-        pa.sh_d[pos] = out.sh_d;
-        pa.sh_c[pos] = out.sh_c;
+    for (uint32_t first = (blockIdx.x / pa.ns) * SHADE_BLOCK; first < n; first += tile_stride) {  // uniform per block; one pass unless LISTED
+        const uint32_t local = first + threadIdx.x;
+        uint32_t flags = 0;
+        ShadeOut out;
+        if (local < n) flags = shade_path(sc, pa, rp, seg0 + (LISTED ? pa.list[seg0 + local] : local), rp.bounce, out);
+        const unsigned long long alive = __ballot((flags & QF_ALIVE) != 0);
+        const unsigned long long shadow = __ballot((flags & QF_SHADOW) != 0);
+        const unsigned long long skipped = __ballot((flags & QF_SKIPPED) != 0);
+        if (lane == 0) {
+            wave_cnt[0][wave] = (uint32_t)__popcll(alive);
+            wave_cnt[1][wave] = (uint32_t)__popcll(shadow);
+            wave_cnt[2][wave] = (uint32_t)__popcll(skipped);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t[3] = {0, 0, 0};
+            for (int w = 0; w < SHADE_BLOCK / 64; ++w)
+                for (int q = 0; q < 3; ++q) t[q] += wave_cnt[q][w];
+            unsigned long long r = 0ull;
+            if (t[0] | t[1]) r = atomicAdd(&pa.acc[oseg * ACC_STRIDE], (unsigned long long)t[0] | ((unsigned long long)t[1] << 32));
+            base[0] = (uint32_t)r;
+            base[1] = (uint32_t)(r >> 32);
+            if (t[2]) atomicAdd(pa.acc_skipped, t[2]);
+        }
+        __syncthreads();
+        if (flags & QF_ALIVE) {
+            uint32_t pos = oseg0 + base[0] + (uint32_t)__popcll(alive & below);
+            for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[0][w];
+            pa.nray_o[pos] = out.o4;
+            pa.nray_d[pos] = out.d4;
+            pa.nbeta[pos] = out.b4;
+            pa.noid[pos] = out.id;
+        }
+        if (flags & QF_SHADOW) {
+            uint32_t pos = oseg0 + base[1] + (uint32_t)__popcll(shadow & below);
+            for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[1][w];
+            pa.sh_o[pos] = make_float4(out.o4.x, out.o4.y, out.o4.z, __uint_as_float(out.id));
+            pa.sh_d[pos] = out.sh_d;
+            pa.sh_c[pos] = out.sh_c;
+        }
+        if (!LISTED) break;
+        __syncthreads();  // the next tile reuses wave_cnt and base
     }
 }
 
@@ -1143,6 +1153,10 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
         const char* e = getenv("RT_LIST_PATHS");
         return e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 18);  // profiles/r03/tuning.md section 11
     }();
+    static const uint32_t shade_tiles = [] {  // RT_SHADE_TILES: blocks per segment of a k_shade launch, each taking every that-many-th tile
+        const char* e = getenv("RT_SHADE_TILES");
+        return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 256u;
+    }();
     static const uint32_t async_below = [] {  // RT_ASYNC_BELOW: bounces with at most this many paths are enqueued
         const char* e = getenv("RT_ASYNC_BELOW");  // without waiting for their exact counts (0: always wait)
         return e ? (uint32_t)strtoul(e, nullptr, 10) : (16u << 20);
@@ -1352,7 +1366,8 @@ int rt_render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_rays* 
                 hipLaunchKernelGGL(k_classify, dim3((seg_ub + CLASSIFY_TILE - 1) / CLASSIFY_TILE * pr.ns), dim3(SHADE_BLOCK), 0, stream, pr, list);
                 ps.list = list;
             }
-            hipLaunchKernelGGL(k_shade, dim3(seg_blocks * pr.ns), dim3(SHADE_BLOCK), 0, stream, ctx->scene, ps, rp);
+            if (ps.list) hipLaunchKernelGGL(k_shade<true>, dim3(std::min(seg_blocks, shade_tiles) * pr.ns), dim3(SHADE_BLOCK), 0, stream, ctx->scene, ps, rp);
+            else hipLaunchKernelGGL(k_shade<false>, dim3(seg_blocks * pr.ns), dim3(SHADE_BLOCK), 0, stream, ctx->scene, ps, rp);
             if ((rc = t_end(2)) != RT_OK) return rc;
             if (ns_of.size() < k + 3) ns_of.resize(k + 3, ns_of[k + 1]);
             ns_of[k + 2] = ns_of[k + 1];  // placeholder until bounce k + 1 decides it (view(k + 1) only uses it for its own shade)
@@ -1481,7 +1496,7 @@ extern "C" int rt_debug_occupancy(int* out4) {  // resident workgroups per CU: e
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_extend<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_shadow<rtd::COUNT_NONE>, RT_BLOCK, 0) != hipSuccess) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_extend_lean<0>, RT_BLOCK, 0) != hipSuccess) return -2;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_shade, SHADE_BLOCK, 0) != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_shade<false>, SHADE_BLOCK, 0) != hipSuccess) return -2;
     return 0;
 }
 extern "C" int rt_debug_trace_stats(unsigned long long* out32, int reset) {
